@@ -1,0 +1,405 @@
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator.  Runs ONLY in the authoring container.
+
+Imports the reference's own classes from /root/reference (read-only) on CPU, feeds them the build's
+deterministic weights / synthetic batches (oracle/vlpythia_ref.py) and writes small ``.npz`` fixtures to
+``tests/golden/``.  The reference never travels to the GPU box; these fixtures do.
+
+Third-party packages the reference imports but the image lacks (timm, wandb, pytorch_lightning, toolz,
+torchmetrics, overrides, torchvision) are satisfied by empty in-process module objects so that the
+reference's *own* code for this path (VLCLIPGPTNeoXForCausalLM, compute_loss, FeatureDistillation,
+DistillationWeights, AdamW, get_linear_schedule_with_warmup) runs verbatim; the frozen vision encoder is
+replaced by an identity feature module (the encoder is the path's input boundary).  Decoder
+arithmetic comes from the installed ``transformers`` GPT-NeoX (5.15.0; upstream pin 4.37.1).
+
+Usage:  PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+import copy
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import vlpythia_ref as R  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __getattr__(self, n):
+        return _Any()
+
+
+def import_reference():
+    import transformers.modeling_utils as mu
+    from transformers import CLIPImageProcessor, CLIPVisionModel  # noqa: F401  (resolve lazies first)
+
+    if not hasattr(mu, "load_sharded_checkpoint"):
+        mu.load_sharded_checkpoint = None
+    t = _stub("timm", __version__="0.9.16")
+    t.models = _stub("timm.models", Eva=type("Eva", (object,), {}))
+    t.data = _stub("timm.data")
+    _stub("wandb", log=lambda *a, **k: None, run=None)
+    _stub("wandb.wandb_run", Run=object)
+    _stub("pytorch_lightning", LightningModule=type("LightningModule", (object,), {}),
+          LightningDataModule=type("LightningDataModule", (object,), {}), Trainer=_Any, seed_everything=lambda s: None)
+    _stub("pytorch_lightning.loggers", WandbLogger=type("WandbLogger", (object,), {}))
+    _stub("pytorch_lightning.utilities")
+    _stub("pytorch_lightning.utilities.rank_zero", rank_zero_only=lambda f: f, rank_zero_warn=lambda *a, **k: None)
+    _stub("pytorch_lightning.callbacks", EarlyStopping=_Any, ModelCheckpoint=_Any, RichProgressBar=_Any)
+    _stub("toolz")
+    _stub("toolz.sandbox", unzip=lambda seq: zip(*seq))
+    _stub("torchmetrics", Metric=type("Metric", (object,), {}))
+    _stub("overrides", overrides=lambda **k: (lambda f: f))
+    _stub("torchvision")
+    _stub("torchvision.transforms", Compose=type("Compose", (object,), {}))
+    import mafed.model.vl_pythia as vp
+    from mafed.methods.distillation import FeatureDistillation
+    from mafed.methods.distillation_loss_weights import DistillationWeights
+    from mafed.optim.adamw import AdamW
+    from mafed.optim.sched import get_linear_schedule_with_warmup
+    return vp, FeatureDistillation, DistillationWeights, AdamW, get_linear_schedule_with_warmup
+
+
+TINY = {
+    # name: dict(h, H, L, V, P, T, B, Dv)   head dims 64 / 128 / 256 mirror 160M-410M / 1.4B / 1B
+    "t64": dict(h=128, H=2, L=3, V=512, P=8, T=6, B=3, Dv=32),
+    "t128": dict(h=256, H=2, L=2, V=256, P=8, T=6, B=2, Dv=32),
+    "t256": dict(h=256, H=1, L=2, V=256, P=8, T=6, B=2, Dv=32),
+    # wider than one wave tile / more tokens than one kv tile, left padding, D=64
+    "m64": dict(h=128, H=2, L=4, V=600, P=40, T=24, B=3, Dv=48),
+}
+
+
+def tiny_cfg(name):
+    t = TINY[name]
+    return R.RefConfig(vocab_size=t["V"], hidden_size=t["h"], num_hidden_layers=t["L"], num_attention_heads=t["H"],
+                       intermediate_size=4 * t["h"], vision_hidden_size=t["Dv"], num_vision_tokens=t["P"])
+
+
+def build_ref_model(vp, cfg: R.RefConfig, sd):
+    from transformers import GPTNeoXConfig
+
+    class FakeVision(torch.nn.Module):
+        def __init__(self, dv):
+            super().__init__()
+            self.num_features = dv
+
+        def forward_features(self, x):
+            return x
+
+    vp.build_vision_encoder = lambda name: FakeVision(cfg.vision_hidden_size)
+    hc = GPTNeoXConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                       num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                       rotary_pct=cfg.rotary_pct, rotary_emb_base=cfg.rotary_emb_base, max_position_embeddings=2048,
+                       layer_norm_eps=cfg.layer_norm_eps, tie_word_embeddings=False, hidden_dropout=0.0,
+                       attention_dropout=0.0, use_parallel_residual=True, attention_bias=True)
+    hc.vision_encoder_name = "fake"
+    hc.select_layer = -2
+    hc.select_feature = "patch"
+    hc._attn_implementation = "eager"
+    model = vp.VLCLIPGPTNeoXForCausalLM(hc)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in k or "vision_encoder" in k for k in missing), missing
+    # the state-dict contract: every trainable name/shape the build generates exists upstream
+    ref_names = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    for k, shp in R.param_shapes(cfg):
+        assert ref_names[k] == shp, (k, ref_names.get(k), shp)
+    return model
+
+
+def ref_batch(batch, drop_labels=False):
+    """Reference batch dict: pixel_values = [B,1+P,Dv] features (CLS row dropped by feature_select)."""
+    f = batch["patch_embeddings"]
+    pv = torch.cat([torch.zeros(f.shape[0], 1, f.shape[2]), f], dim=1)
+    out = {"input_ids": batch["input_ids"].clone(), "attention_mask": batch["attention_mask"].clone(), "pixel_values": pv}
+    if not drop_labels:
+        out["labels"] = batch["labels"].clone()
+    return out
+
+
+def np_(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def grads_summary(model, cfg):
+    names = [k for k, _ in R.param_shapes(cfg)]
+    named = dict(model.named_parameters())
+    norms = np.array([float(named[k].grad.norm()) if named[k].grad is not None else 0.0 for k in names], np.float64)
+    total = float(torch.linalg.vector_norm(torch.stack([named[k].grad.norm() for k in names if named[k].grad is not None])))
+    keep = ["gpt_neox.final_layer_norm.weight", "gpt_neox.layers.0.attention.query_key_value.bias",
+            "gpt_neox.layers.0.input_layernorm.weight", "gpt_neox.layers.0.post_attention_layernorm.bias",
+            "gpt_neox.layers.1.mlp.dense_4h_to_h.bias", "gpt_neox.layers.1.attention.dense.weight",
+            "gpt_neox.layers.0.mlp.dense_h_to_4h.weight", "vision_embed_tokens.0.bias", "vision_embed_tokens.2.weight"]
+    full = {}
+    for k in keep:  # 1-D grads in full; matrices as first 4 rows + row/column sums (keeps fixtures small)
+        g = named[k].grad
+        if g.dim() == 1:
+            full["grad/" + k] = np_(g)
+        else:
+            full["grad/" + k + "/rows4"] = np_(g[:4])
+            full["grad/" + k + "/rowsum"] = np_(g.sum(-1))
+            full["grad/" + k + "/colsum"] = np_(g.sum(0))
+    # embedding rows that were actually used + head rows of the label ids
+    full["grad/gpt_neox.embed_in.weight/rowsum"] = np_(named["gpt_neox.embed_in.weight"].grad.sum(-1))
+    full["grad/embed_out.weight/rowsum"] = np_(named["embed_out.weight"].grad.sum(-1))
+    return names, norms, total, full
+
+
+def gen_model_fixture(name, refs, seed=7):
+    vp, FD, DW, AdamW, sched = refs
+    cfg = tiny_cfg(name)
+    t = TINY[name]
+    sd = R.init_weights(cfg, seed=seed, bias_std=0.02, ln_jitter=0.05)
+    tsd = R.perturb(sd, seed=seed + 100, std=5e-3)
+    batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 1, pad=True, n_answer=3)
+    out = {"meta/seed": seed, "meta/name": name}
+    for k, v in batch.items():
+        out["batch/" + k] = np_(v)
+    out["meta/weight_checksum"] = float(sum(v.double().abs().sum() for v in sd.values()))
+
+    # --- G1/G2: naive forward + backward -------------------------------------------------------
+    model = build_ref_model(vp, cfg, sd)
+    model.train()
+    o = model(**ref_batch(batch), output_hidden_states=True, return_dict=True)
+    assert len(o.hidden_states) == cfg.num_hidden_layers + 1
+    out["g1/loss"] = float(o.loss)
+    out["g1/logits_text"] = np_(o.logits[:, -t["T"]:])
+    for i, hsi in enumerate(o.hidden_states):
+        out[f"g1/hidden/{i}"] = np_(hsi)
+    o.loss.backward()
+    names, norms, total, full = grads_summary(model, cfg)
+    out["g2/grad_norms"] = norms
+    out["g2/grad_norm_total"] = total
+    out.update({"g2/" + k: v for k, v in full.items()})
+
+    # --- G3: MAFED replay step variants ---------------------------------------------------------
+    teacher_src = build_ref_model(vp, cfg, tsd)
+    opts = types.SimpleNamespace(tasks=["a", "b", "c"], batch_size=t["B"], seed=42, pin_mem=False, accumulate_grad_batches=1)
+    nh = cfg.num_hidden_layers - 1
+    variants = [
+        ("balanced_discounted_g05_mse", dict(distillation_modality_weighing_strategy="balanced",
+                                             distillation_layer_weighing_strategy="discounted", gamma=0.5, distillation_layer=None)),
+        ("equal_discounted_g09_mse", dict(distillation_modality_weighing_strategy="equal",
+                                          distillation_layer_weighing_strategy="discounted", gamma=0.9, distillation_layer=None)),
+        ("equal_equal_mse", dict(distillation_modality_weighing_strategy="equal",
+                                 distillation_layer_weighing_strategy="equal", distillation_layer=None)),
+        ("balanced_single_mse", dict(distillation_modality_weighing_strategy="balanced",
+                                     distillation_layer_weighing_strategy="single", distillation_layer=min(1, nh - 1))),
+        ("balanced_discounted_g05_cosine", dict(distillation_modality_weighing_strategy="balanced",
+                                                distillation_layer_weighing_strategy="discounted", gamma=0.5,
+                                                distillation_layer=None, distillation_loss="cosine")),
+        ("cls_cosine", dict(distillation_modality_weighing_strategy="balanced",
+                            distillation_layer_weighing_strategy="discounted", gamma=0.5, distillation_layer=None,
+                            distillation_loss="cosine", cls_distillation=True)),
+        ("adaptive_discounted_g05_mse", dict(distillation_modality_weighing_strategy="adaptive",
+                                             distillation_layer_weighing_strategy="discounted", gamma=0.5, distillation_layer=None)),
+    ]
+    if nh >= 2:
+        variants.append(("balanced_cumulative_mse", dict(distillation_modality_weighing_strategy="balanced",
+                                                         distillation_layer_weighing_strategy="cumulative",
+                                                         distillation_layer=nh - 1)))
+    adaptive_vec = torch.linspace(0.3, 0.8, nh)
+    for vname, kw in variants:
+        model = build_ref_model(vp, cfg, sd)
+        model.train()
+        fd = FD(memory_size=100, opts=opts, model_type="vlpythia", num_hidden_layers=nh, distillation_coeff=1.5,
+                replay_coeff=0.7, **kw)
+        fd._update_model(teacher_src)
+        fd.task_id = 1
+        fd.num_vision_tokens = cfg.num_vision_tokens
+        fd.loss_weights.num_vision_tokens = cfg.num_vision_tokens
+        if kw["distillation_modality_weighing_strategy"] == "adaptive":
+            fd.loss_weights.lang_coeff = adaptive_vec.clone()
+            out["g3/adaptive_lang_coeff"] = np_(adaptive_vec)
+        captured = {}
+        orig = fd._compute_distillation_loss
+
+        def spy(hidden_states, past_hidden_states, mask, _orig=orig, _c=captured):
+            v = _orig(hidden_states=hidden_states, past_hidden_states=past_hidden_states, mask=mask)
+            _c.setdefault("vals", []).append(float(v))
+            return v
+
+        fd._compute_distillation_loss = spy
+        rb = ref_batch(batch)
+        fd.mem_dataloader = [rb]
+        loss, n_ex = fd.replay(model)
+        assert "labels" not in rb and ("lang_masks" in rb or kw.get("cls_distillation"))  # side effects, SURVEY A13/A15
+        loss.backward()
+        _, norms, total, full = grads_summary(model, cfg)
+        pre = f"g3/{vname}/"
+        out[pre + "loss"] = float(loss)
+        out[pre + "n_ex"] = int(n_ex)
+        out[pre + "per_call_losses"] = np.array(captured.get("vals", []), np.float64)  # [lang_l0, vis_l0, lang_l1, ...]
+        out[pre + "layers"] = np.array(fd.loss_weights.get_distillation_layers(), np.int64)
+        lc = fd.loss_weights.layer_coeffs
+        out[pre + "layer_coeffs"] = np_(lc) if lc is not None else np.array([1.0], np.float32)
+        out[pre + "grad_norms"] = norms
+        out[pre + "grad_norm_total"] = total
+        for k in ("grad/gpt_neox.layers.0.input_layernorm.weight", "grad/vision_embed_tokens.0.bias",
+                  "grad/gpt_neox.layers.1.attention.dense.weight/rows4"):
+            out[pre + k] = full[k]
+
+    # --- G7: adaptive modality weights pass (between-task; section 8f-2) ---------------------------
+    model = build_ref_model(vp, cfg, sd)
+    dw = DW(distillation_modality_weighing_strategy="adaptive", distillation_layer_weighing_strategy="discounted",
+            gamma=0.5, num_hidden_layers=nh, distillation_layer=None, num_vision_tokens=cfg.num_vision_tokens)
+    b2 = R.make_batch(cfg, t["B"], t["T"], seed=seed + 2, pad=True, n_answer=3)
+    out["g7/lang_importances"] = np_(dw.compute_adaptive_weights(model, [ref_batch(batch), ref_batch(b2)]))
+    for k, v in b2.items():
+        out["g7/batch2/" + k] = np_(v)
+
+    np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **out)
+    print(name, "loss", out["g1/loss"], "gn", out["g2/grad_norm_total"])
+
+
+def gen_trainer_fixture(refs, name="t64", seed=11):
+    """8 micro-batches, task 1, replay_interval=4, accumulate=4 (scripts/run_seed42.sh:59,68-69), hook order of
+    SURVEY.md 8b(3): training_step -> loss/accum -> backward -> [clip 2.0 -> AdamW -> LambdaLR] on window end."""
+    vp, FD, DW, AdamW, sched = refs
+    cfg = tiny_cfg(name)
+    t = TINY[name]
+    sd = R.init_weights(cfg, seed=seed, bias_std=0.02, ln_jitter=0.05)
+    tsd = R.perturb(sd, seed=seed + 100, std=5e-3)
+    model = build_ref_model(vp, cfg, sd)
+    model.train()
+    teacher_src = build_ref_model(vp, cfg, tsd)
+    opts = types.SimpleNamespace(tasks=["a", "b", "c"], batch_size=t["B"], seed=42, pin_mem=False, accumulate_grad_batches=4)
+    fd = FD(memory_size=100, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+            distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+            gamma=0.5, distillation_layer=None, distillation_coeff=1.0, replay_coeff=1.0)
+    fd._update_model(teacher_src)
+    fd.task_id = 1
+    fd.num_vision_tokens = cfg.num_vision_tokens
+    # optimiser exactly as configure_optimizers builds it (vqa_cont_learner.py:71-128)
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight", "vqa_output_distill_loss_params"]
+    named = [(n, p) for n, p in model.named_parameters()]
+    lr, wd, lr_mul = 1e-3, 0.01, 10.0
+    groups = [
+        {"params": [p for n, p in named if "vqa_output" in n and not any(nd in n for nd in no_decay)], "lr": lr_mul * lr, "weight_decay": wd},
+        {"params": [p for n, p in named if "vqa_output" in n and any(nd in n for nd in no_decay)], "lr": lr_mul * lr, "weight_decay": 0.0},
+        {"params": [p for n, p in named if "vqa_output" not in n and not any(nd in n for nd in no_decay)], "lr": lr, "weight_decay": wd},
+        {"params": [p for n, p in named if "vqa_output" not in n and any(nd in n for nd in no_decay)], "lr": lr, "weight_decay": 0.0},
+    ]
+    opt = AdamW(groups, lr=lr, betas=(0.9, 0.98))
+    total_steps, warm = 20, 2
+    sch = sched(opt, warm, total_steps, last_epoch=-1)
+    accum, interval = 4, 4
+    recs = {"branch": [], "loss": [], "grad_norm": [], "lr": [], "checksum": []}
+    out = {"meta/seed": seed, "meta/name": name, "meta/lr": lr, "meta/total_steps": total_steps, "meta/warmup": warm}
+    for bi in range(8):
+        batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 10 + bi, pad=True, n_answer=3)
+        mem = R.make_batch(cfg, t["B"], t["T"], seed=seed + 50 + bi, pad=True, n_answer=3)
+        loss = None
+        if (bi + 1) % interval == 0:
+            fd.mem_dataloader = [ref_batch(mem)]
+            loss, _ = fd.replay(model)
+            recs["branch"].append(1)
+        if loss is None:
+            loss = model(**ref_batch(batch), compute_loss=True, return_dict=True).loss
+            loss = fd.compute_loss(model, loss, batch=batch)
+            recs["branch"].append(0)
+        recs["loss"].append(float(loss))
+        (loss / accum).backward()
+        if (bi + 1) % accum == 0:
+            fd.update_after_backward(model=model)
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0)
+            recs["grad_norm"].append(float(gn))
+            recs["lr"].append(opt.param_groups[2]["lr"])
+            opt.step()
+            sch.step()
+            opt.zero_grad()
+            recs["checksum"].append(float(sum(p.detach().double().sum() for n, p in model.named_parameters())))
+        fd.update_after_step(model=model, batch_idx=bi)
+    for k, v in recs.items():
+        out["seq/" + k] = np.array(v, np.float64)
+    fin = dict(model.named_parameters())
+    for k in ("gpt_neox.final_layer_norm.weight", "gpt_neox.layers.0.attention.query_key_value.bias"):
+        out["final/" + k] = np_(fin[k])
+    for k in ("gpt_neox.layers.1.attention.dense.weight", "vision_embed_tokens.2.weight"):
+        out["final/" + k + "/rows4"] = np_(fin[k][:4])
+    np.savez_compressed(os.path.join(OUT, f"trainer_{name}.npz"), **out)
+    print("trainer", recs["loss"], recs["grad_norm"], recs["lr"])
+
+
+def gen_optim_fixture(refs):
+    """G4 (layer coefficient vectors) + G5 (AdamW / LambdaLR known answers)."""
+    vp, FD, DW, AdamW, sched = refs
+    out = {}
+    for nh in (11, 15, 23):
+        for g in (0.5, 0.8, 0.9):
+            dw = DW(distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                    gamma=g, num_hidden_layers=nh, distillation_layer=None)
+            out[f"g4/discounted/nh{nh}/g{g}"] = np_(dw.layer_coeffs)
+        dw = DW(distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="equal",
+                num_hidden_layers=nh, distillation_layer=None)
+        out[f"g4/equal/nh{nh}"] = np_(dw.layer_coeffs)
+    rng = np.random.default_rng(5)
+    p0 = rng.standard_normal((37, 19)).astype(np.float32)
+    b0 = rng.standard_normal((19,)).astype(np.float32)
+    gs = [(rng.standard_normal((37, 19)).astype(np.float32), rng.standard_normal((19,)).astype(np.float32)) for _ in range(3)]
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    b = torch.nn.Parameter(torch.from_numpy(b0.copy()))
+    opt = AdamW([{"params": [p], "weight_decay": 0.01}, {"params": [b], "weight_decay": 0.0}], lr=5e-3, betas=(0.9, 0.98))
+    sch = sched(opt, 2, 10, last_epoch=-1)
+    out["g5/p0"], out["g5/b0"] = p0, b0
+    lrs = []
+    for i, (gp, gb) in enumerate(gs):
+        p.grad, b.grad = torch.from_numpy(gp.copy()), torch.from_numpy(gb.copy())
+        gn = torch.nn.utils.clip_grad_norm_([p, b], 2.0)
+        out[f"g5/step{i}/gp"], out[f"g5/step{i}/gb"] = gp, gb
+        out[f"g5/step{i}/grad_norm"] = float(gn)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        out[f"g5/step{i}/p"], out[f"g5/step{i}/b"] = np_(p.data.clone()), np_(b.data.clone())
+    out["g5/lrs"] = np.array(lrs, np.float64)
+    opt2 = AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    s2 = sched(opt2, 3, 12, last_epoch=-1)
+    lam = []
+    for _ in range(14):
+        lam.append(opt2.param_groups[0]["lr"])
+        opt2.step()
+        s2.step()
+    out["g5/lambda_w3_t12"] = np.array(lam, np.float64)
+    np.savez_compressed(os.path.join(OUT, "optim.npz"), **out)
+    print("optim fixture ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    import logging
+    import transformers
+    transformers.logging.set_verbosity_error()
+    logging.disable(logging.INFO)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    refs = import_reference()
+    for name in TINY:
+        gen_model_fixture(name, refs)
+    gen_trainer_fixture(refs)
+    gen_optim_fixture(refs)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import vlpythia_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY = {
+    "t64": dict(h=128, H=2, L=3, V=512, P=8, T=6, B=3, Dv=32),
+    "t128": dict(h=256, H=2, L=2, V=256, P=8, T=6, B=2, Dv=32),
+    "t256": dict(h=256, H=1, L=2, V=256, P=8, T=6, B=2, Dv=32),
+    "m64": dict(h=128, H=2, L=4, V=600, P=40, T=24, B=3, Dv=48),
+}
+
+
+def tiny_cfg(name):
+    t = TINY[name]
+    return R.RefConfig(vocab_size=t["V"], hidden_size=t["h"], num_hidden_layers=t["L"], num_attention_heads=t["H"],
+                       intermediate_size=4 * t["h"], vision_hidden_size=t["Dv"], num_vision_tokens=t["P"])
+
+
+def load_golden(fname):
+    return np.load(os.path.join(GOLDEN, fname), allow_pickle=False)
+
+
+def golden_setup(name):
+    """(cfg, student weights, teacher weights, batch, golden) exactly as oracle/gen_golden.py built them."""
+    g = load_golden(f"model_{name}.npz")
+    cfg = tiny_cfg(name)
+    seed = int(g["meta/seed"])
+    sd = R.init_weights(cfg, seed=seed, bias_std=0.02, ln_jitter=0.05)
+    chk = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(chk - float(g["meta/weight_checksum"])) < 1e-6 * chk, "deterministic weight generator drifted"
+    tsd = R.perturb(sd, seed=seed + 100, std=5e-3)
+    batch = {k: torch.from_numpy(g["batch/" + k]) for k in ("input_ids", "attention_mask", "labels", "patch_embeddings")}
+    return cfg, sd, tsd, batch, g
+
+
+G3_VARIANTS = {
+    "balanced_discounted_g05_mse": dict(modality="balanced", layer_strategy="discounted", gamma=0.5),
+    "equal_discounted_g09_mse": dict(modality="equal", layer_strategy="discounted", gamma=0.9),
+    "equal_equal_mse": dict(modality="equal", layer_strategy="equal"),
+    "balanced_single_mse": dict(modality="balanced", layer_strategy="single", distillation_layer="min1"),
+    "balanced_discounted_g05_cosine": dict(modality="balanced", layer_strategy="discounted", gamma=0.5, loss="cosine"),
+    "cls_cosine": dict(modality="balanced", layer_strategy="discounted", gamma=0.5, loss="cosine", cls=True),
+    "adaptive_discounted_g05_mse": dict(modality="adaptive", layer_strategy="discounted", gamma=0.5),
+    "balanced_cumulative_mse": dict(modality="balanced", layer_strategy="cumulative", distillation_layer="nh-1", gamma=0.8),
+}
+
+
+def g3_spec(vname, cfg, g):
+    kw = dict(G3_VARIANTS[vname])
+    nh = cfg.num_hidden_layers - 1
+    if kw.get("distillation_layer") == "min1":
+        kw["distillation_layer"] = min(1, nh - 1)
+    elif kw.get("distillation_layer") == "nh-1":
+        kw["distillation_layer"] = nh - 1
+    if kw["modality"] == "adaptive":
+        kw["lang_coeff"] = torch.from_numpy(g["g3/adaptive_lang_coeff"])
+    return R.DistillSpec(distillation_coeff=1.5, replay_coeff=0.7, **kw)
