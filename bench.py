@@ -1,0 +1,184 @@
+"""Headline benchmark: train samples/s of the MAFED distill step, VLPythia-410M, 256 image + 32 text tokens,
+batch 32 per GPU (BASELINE.json metric / configs[2]); N = 1, 2, 4, 8 GPUs of one node, one process per GPU over RCCL.
+
+A "step" = one full MAFED optimiser step on one synthetic memory batch resident in HBM: student forward with hidden
+states + frozen-teacher forward + replay cross-entropy + (L-1)-layer per-modality distillation MSE + backward +
+global-norm clip + AdamW (accumulate 1, replay on every step: SURVEY.md section 8d "primary").  Nothing is skipped or
+cached inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model 410m] [--batch 32] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table (never the 2:1-sparsity figure)
+
+
+def algorithmic_flops_per_sample(h, L, V, P, T, dv, distill=True):
+    """SURVEY.md section 8d conventions: 2 flops/MAC; 24 h^2 per token per layer; causal attention 4 h S(S+1)/2 per layer;
+    LM head on the T text positions; projector 2 (dv h + h^2) P; backward = 2x forward; teacher = (L-2)/L of the layer
+    stack + projector, no head, no backward."""
+    S = P + T
+    stack = L * (24.0 * h * h * S + 4.0 * h * S * (S + 1) / 2.0)
+    head = 2.0 * h * V * T
+    proj = 2.0 * (dv * h + h * h) * P
+    fwd = stack + head + proj
+    total = 3.0 * fwd
+    if distill:
+        total += stack * (L - 2) / L + proj
+    return total
+
+
+def cpu_baseline(model_name, P, T, seconds_hint=20.0):
+    """The oracle (CPU restatement of the reference path, fp32 eager) timed on this box's host cores on a bounded sample
+    of the same workload: same model / sequence shape / MAFED step, batch 4 instead of 32."""
+    from oracle import vlpythia_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 4
+    cfg = R.preset(model_name, num_vision_tokens=P)
+    sd = R.init_weights(cfg, seed=1234)
+    tsd = {k: v + 1e-3 * torch.randn(v.shape, generator=torch.Generator().manual_seed(1237)) for k, v in sd.items()}
+    batch = R.make_batch(cfg, B, T, seed=1235, pad=False)
+    tr = R.RefTrainer(cfg, sd, lr=5e-5, accumulate=1, replay_interval=1, warmup_steps=0, total_steps=1000, task_id=1, teacher_sd=tsd,
+                      spec=R.DistillSpec(modality="balanced", layer_strategy="discounted", gamma=0.5))
+    tr.step(batch, 0, batch)  # warm-up
+    n, t0 = 0, time.time()
+    while n < 2 or (time.time() - t0 < seconds_hint and n < 8):
+        tr.step(batch, n + 1, batch)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 CPU, VLPythia-{model_name}+MAFED distill step, batch {B} (of 32), {P} img + {T} txt tokens, {n} timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="410m")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--img-tokens", type=int, default=256)
+    ap.add_argument("--txt-tokens", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-events", action="store_true")
+    args = ap.parse_args()
+
+    from mafed_amd import FeatureDistillation, Trainer, VLPythiaConfig, VLPythiaForCausalLM, ops
+    from mafed_amd.dist import broadcast_teacher, init_from_env
+    from mafed_amd.methods import HBMReplayBuffer
+    import torch.distributed as dist
+
+    rank, local, world = init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (mafed_amd has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, P, T = args.batch, args.img_tokens, args.txt_tokens
+    cfg = VLPythiaConfig.preset(args.model, num_vision_tokens=P)
+    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    # synthetic inputs of SURVEY.md section 8d: weights N(0, 0.02) (HF init), teacher = student + N(0, 1e-3)
+    student = VLPythiaForCausalLM(cfg, compute_dtype=cd, device=dev, seed=1234)
+    opts = types.SimpleNamespace(tasks=["t0", "t1"], batch_size=B, seed=1236, pin_mem=False, accumulate_grad_batches=1)
+    fd = FeatureDistillation(memory_size=4000, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                             distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                             gamma=0.5, distillation_layer=None, distillation_coeff=1.0, replay_coeff=1.0)
+    fd._update_model(student)
+    g = torch.Generator(device=dev).manual_seed(1237)
+    fd.past_model.flat_params.add_(torch.randn(fd.past_model.flat_params.shape, generator=g, device=dev) * 1e-3)
+    fd.past_model._shadow_dirty = True
+    broadcast_teacher(fd.past_model)
+    fd.task_id = 1
+    fd.num_vision_tokens = P
+    n_mem = 8 * B
+    gcpu = torch.Generator().manual_seed(1235 + rank)
+    ids = torch.randint(1, cfg.vocab_size, (n_mem, T), generator=gcpu)
+    labels = torch.full((n_mem, T), -100, dtype=torch.int64)
+    labels[:, -4:] = ids[:, -4:]
+    mem = HBMReplayBuffer(B, dev, seed=1236 + rank)
+    mem.add({"input_ids": ids, "attention_mask": torch.ones(n_mem, T, dtype=torch.int64), "labels": labels,
+             "patch_embeddings": torch.randn(n_mem, P, cfg.vision_hidden_size, generator=torch.Generator().manual_seed(1234 + rank))})
+    fd.mem_dataloader = mem
+    conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=1, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
+                                 weight_decay=0.01, optim="adamw", warmup_perc=0.1)
+    tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1)
+    task_batch = mem.sample()  # dropped by a replay step, as in the reference
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        tr.step(task_batch, i)
+    torch.cuda.synchronize()
+    barrier()
+    if rank == 0 and not args.no_gemm_events:
+        ops.GEMM_EVENTS = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rec = tr.step(task_batch, args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = float(rec["loss"])
+    assert loss == loss, "NaN loss in the timed region"
+
+    if rank == 0:
+        samples = args.steps * B * world
+        value = samples / dt
+        flops_step = algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size) * B
+        roof = None
+        if ops.GEMM_EVENTS:
+            ev = ops.GEMM_EVENTS
+            ops.GEMM_EVENTS = None
+            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            fl = sum(f for _, _, f in ev)
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None, "kernel": "gemm_bf16_kernel (all bf16 MFMA GEMM launches of the timed region)",
+                    "launches": len(ev), "avg_launch_us": round(ms * 1e3 / len(ev), 2), "avg_gflop_per_launch": round(fl / len(ev) / 1e9, 3),
+                    "gemm_share_of_step_time": round(ms * 1e-3 / dt, 4)}
+        out = {"metric": "train samples/sec VLPythia-410M+MAFED, 256img+32txt tok, bs=32, 1/2/4/8 GPU" if args.model == "410m" else
+               f"train samples/sec VLPythia-{args.model}+MAFED", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"VLPythia-{args.model} + MAFED distill step (student fwd+bwd, frozen-teacher fwd, replay CE, "
+                          f"{cfg.num_hidden_layers - 1}-layer per-modality MSE, clip 2.0, AdamW), {P} img + {T} txt tokens",
+                          "global_batch": B * world, "per_gpu_batch": B, "seq_len": P + T, "parallelism": f"dp{world}",
+                          "random_init_weights": True},
+               "step_tflops_algorithmic": round(flops_step / 1e12, 3),
+               "mfma_frac_whole_step": round(flops_step * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5)}
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.model, P, T)
+            except Exception as e:  # the CPU leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * mafed_hip.h -- C-ABI of the MI355X-native (gfx950) MAFED training hot path.
+ *
+ * The reference (MalvinaNikandrou/mafed) is pure Python and has no FFI of its own; the arithmetic of its
+ * per-step path lives in torch / transformers / flash-attn calls.  Each entry point below names the reference
+ * call site it replaces (paths relative to the reference checkout; "tf:" = transformers
+ * models/gpt_neox/modeling_gpt_neox.py).  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; row-major, contiguous unless an ld is given
+ *   - `stream` is a hipStream_t passed as void*; every launch goes on it; nothing allocates, synchronises or throws
+ *   - return 0 on success, a negative MAFED_E* code otherwise (mafed_last_error_string() has the detail)
+ *   - dtype arguments use mafed_dtype; the fp32 residual stream / statistics / gradients of parameters are float
+ *   - parameter-gradient outputs ACCUMULATE (+=): the host zeroes the flat gradient buffer once per
+ *     accumulation window (Lightning accumulate_grad_batches semantics, mafed/train.py:286)
+ */
+#ifndef MAFED_HIP_H
+#define MAFED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MAFED_F32 = 0, MAFED_BF16 = 1 } mafed_dtype;
+
+enum {
+  MAFED_OK = 0,
+  MAFED_EINVAL = -1,   /* bad shape / alignment / unsupported combination */
+  MAFED_ELAUNCH = -2,  /* hipLaunch / hipGetLastError failed */
+  MAFED_EWORKSPACE = -3 /* workspace too small */
+};
+
+/* GEMM epilogues (mafed_gemm.epilogue) */
+enum {
+  MAFED_EPI_NONE = 0,
+  MAFED_EPI_GELU = 1,     /* C = gelu_erf(acc + bias); aux (if non-NULL) receives the pre-activation acc + bias */
+  MAFED_EPI_GELU_BWD = 2  /* C = (acc) * gelu_erf'(aux) ; aux = saved pre-activation, same dtype as C */
+};
+
+int mafed_version(void);
+const char* mafed_last_error_string(void);
+
+/* ---- dense contractions -------------------------------------------------------------------------------
+ * C[M,N] = op(A)[M,K] . op(B)[K,N]  (+ bias[n]) -> epilogue -> (+ res1 + res2) (+ beta * C_old)
+ *   transA == 0: A stored [M,K] (lda >= K)     transA == 1: A stored [K,M] (lda >= M)
+ *   transB == 0: B stored [K,N] (ldb >= N)     transB == 1: B stored [N,K] (ldb >= K)   (nn.Linear weight)
+ * in_dtype MAFED_BF16: MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulate; MAFED_F32: exact fp32 FMA path (parity mode).
+ * c_dtype may be F32 or BF16; res1/res2 are fp32 [M,N] (ld = ldc) or NULL; beta != 0 requires c_dtype F32.
+ * Replaces: every nn.Linear on the path -- query_key_value / dense (tf:192-193,204,233), dense_h_to_4h /
+ * dense_4h_to_h + GELU (tf:38-49), vision_embed_tokens (mafed/model/vl_pythia.py:226-234,270), embed_out (:213,310),
+ * their autograd backward (dX = dY.W, dW += dY^T.X), and the parallel-residual add (tf:271-274) via res1/res2.
+ */
+int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+               const void* A, int64_t lda, const void* B, int64_t ldb,
+               void* C, int64_t ldc, mafed_dtype c_dtype,
+               const float* bias, int epilogue, void* aux,
+               const float* res1, const float* res2, float beta, void* stream);
+
+/* out[n] += sum_m X[m,n]   (bias gradients; X dtype bf16/f32, out fp32 accumulate).  workspace: >= colsum_workspace_bytes */
+size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N);
+int mafed_colsum(const void* X, mafed_dtype dtype, int64_t M, int64_t N, int64_t ldx, float* out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm (tf:243-244,313: nn.LayerNorm, eps 1e-5) ---------------------------------------------------
+ * Dual-affine: with use_parallel_residual both LNs of a layer normalise the same tensor (tf:261,272), so x is read
+ * once and two outputs are written.  Pass w2 = b2 = y2 = NULL for a single LN (final_layer_norm).
+ * x fp32 [rows,h]; y1/y2 in out_dtype; mean/rstd fp32 [rows] saved for backward (may be NULL for inference).
+ */
+int mafed_layernorm_fwd(const float* x, int64_t rows, int h, float eps,
+                        const float* w1, const float* b1, void* y1,
+                        const float* w2, const float* b2, void* y2,
+                        mafed_dtype out_dtype, float* mean, float* rstd, void* stream);
+/* dx = LN'(dy1;w1) + LN'(dy2;w2) + dres ; optional dx_lp = dx cast to dy_dtype (the next GEMM's operand).
+ * dy1/dy2 in dy_dtype (dy2, w2, dw2, db2 NULL for single LN); dres fp32 [rows,h] or NULL (the residual-stream
+ * gradient flowing around the layer); dx fp32 [rows,h] (may alias dres).  dw1/db1/dw2/db2 fp32 [h], accumulated.
+ * Optional fused distillation-gradient injection (the hidden state this LN normalises is a distilled one,
+ * mafed/methods/distillation.py:237-249 backward): if teacher != NULL,
+ *   dx[row,:] += inj_scale[row_class] * (x - teacher)   with row_class from (row % S): <P image, text-valid, pad=none
+ * where inj_scale_host = {lang_scale, vision_scale} already contains 2/h * coeff * weight / count * upstream grad. */
+size_t mafed_layernorm_bwd_workspace_bytes(int64_t rows, int h);
+int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype,
+                        const float* x, const float* mean, const float* rstd,
+                        const float* w1, const float* w2, int64_t rows, int h,
+                        const float* dres, float* dx, void* dx_lp,
+                        float* dw1, float* db1, float* dw2, float* db2,
+                        const float* teacher, const int64_t* attention_mask, int S, int P, int T,
+                        const float* inj_scale_dev /* [2] device: {lang, vision} or NULL */,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- attention (tf:154-236 eager path / flash-attn-2 wheel, README.md:16) ------------------------------------
+ * qkv: [B,S,H,3,D] exactly as the fused query_key_value GEMM leaves it (per-head {q,k,v} interleave, tf:204-207).
+ * Partial rotary (first rot dims, NeoX rotate_half pairing, position = row index, tf:111-151) is applied to q and k
+ * on load; rot_cos/rot_sin fp32 [S, rot/2].  Fully causal over S, plus key-padding from attention_mask [B,T]
+ * (int64, 1 = valid; LEFT padded so invalid keys are the contiguous range [P, P+pad_b)); P = S - T image keys are
+ * always valid.  softmax in fp32; scale = D^-0.5.  out [B,S,H*D] in dtype; lse fp32 [B,H,S] (natural log).
+ * dtype BF16: MFMA kernels (D in {64,128}); F32: exact parity kernels (D <= 256).
+ */
+int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, int H, int D, int rot,
+                   const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T,
+                   void* out, float* lse, void* stream);
+/* dqkv [B,S,H,3,D] (dtype) <- d(out); inverse rotation applied to dq, dk.  delta fp32 [B,H,S] scratch. */
+int mafed_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype,
+                   int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                   const int64_t* attention_mask, int T, void* dqkv, float* delta, void* stream);
+
+/* ---- embedding + concat (mafed/model/vl_pythia.py:282-283) ---------------------------------------------------
+ * h0[b, :P] = image[b] ; h0[b, P:] = embed_in[input_ids[b]]  -> fp32 [B,P+T,h].  image in img_dtype [B,P,h]. */
+int mafed_embed_concat_fwd(const void* image, mafed_dtype img_dtype, const float* embed_in, const int64_t* input_ids,
+                           int B, int P, int T, int h, int64_t V, float* h0, void* stream);
+/* d_image[b] = dh0[b,:P] (img_dtype) ; d_embed_in[input_ids[b,t]] += dh0[b,P+t] (fp32 atomics) */
+int mafed_embed_concat_bwd(const float* dh0, const int64_t* input_ids, int B, int P, int T, int h, int64_t V,
+                           void* d_image, mafed_dtype img_dtype, float* d_embed_in, void* stream);
+
+/* ---- per-sample-normalised shifted cross-entropy (mafed/model/vl_pythia.py:44-96) ---------------------------
+ * logits [B,T,V] (text positions only), labels int64 [B,T]; row (b,t) predicts labels[b,t+1]; ignore_index -100;
+ * loss = mean_b( sum_t ce[b,t] / max(count_b, 1e-13) ).  lse fp32 [B,T] saved.  loss_out fp32 [1]. */
+int mafed_ce_fwd(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V,
+                 float* lse, float* row_loss /* [B,T] scratch */, float* loss_out, void* stream);
+/* dlogits[b,t,:] = gloss * (softmax - onehot) / (B * count_b) for valid rows, 0 otherwise (incl. t = T-1).
+ * gloss_dev: device scalar (upstream dL/dloss).  dlogits may alias logits. */
+int mafed_ce_bwd(const void* logits, mafed_dtype dtype, const int64_t* labels, const float* lse, int B, int T, int64_t V,
+                 const float* gloss_dev, void* dlogits, void* stream);
+
+/* ---- MAFED per-modality masked distillation (mafed/methods/distillation.py:124-166, 226-257) -----------------
+ * s, t: fp32 [B,S,h] student / frozen-teacher hidden state of one layer; attention_mask int64 [B,T]; P image tokens.
+ * One pass serves both masks: out[4] = { sum_lang d, sum_vision d, n_lang, n_vision } with
+ *   mse:    d[row] = sum((s-t)^2)/h                      (_compute_mse_distillation_loss, :237-249)
+ *   cosine: d[row] = 1 - cos(s,t)  (CosineEmbeddingLoss target 1, eps 1e-8 inside the norms; :226-235)
+ * Deterministic two-stage reduction (no float atomics).  workspace >= mafed_distill_workspace_bytes(B*S). */
+size_t mafed_distill_workspace_bytes(int64_t rows);
+int mafed_distill_fwd(const float* s, const float* t, const int64_t* attention_mask, int B, int S, int P, int h,
+                      int cosine, float* out4, void* workspace, size_t workspace_bytes, void* stream);
+/* ds (+)= g_lang[row] / g_vision[row] weighted gradient of the above:  coef_dev[2] = {c_lang, c_vision} where the
+ * host/torch side already folded upstream grad * layer_coeff * distillation_coeff * modality weight / count.
+ *   mse:    ds = c * 2/h * (s - t)
+ *   cosine: ds = c * -( t/(|s||t|) - cos * s/|s|^2 )
+ * accumulate != 0 adds into ds, else overwrites (rows of no modality get 0). */
+int mafed_distill_bwd(const float* s, const float* t, const int64_t* attention_mask, int B, int S, int P, int h,
+                      int cosine, const float* coef_dev, float* ds, int accumulate, void* stream);
+/* CLS variant (:251-257): token 0 only, cosine, mean over batch -> out[1]; bwd with coef_dev[1] = upstream/B */
+int mafed_distill_cls_fwd(const float* s, const float* t, int B, int S, int h, float* out1, void* stream);
+int mafed_distill_cls_bwd(const float* s, const float* t, int B, int S, int h, const float* coef_dev, float* ds,
+                          int accumulate, void* stream);
+
+/* ---- optimiser side -------------------------------------------------------------------------------------------
+ * Global L2 norm of a flat fp32 gradient buffer (Lightning gradient_clip_val -> clip_grad_norm_, mafed/train.py:288):
+ * out[0] = ||g||_2, out[1] = clip scale = min(1, max_norm / (norm + 1e-6)).  workspace >= gradnorm_workspace_bytes. */
+size_t mafed_gradnorm_workspace_bytes(int64_t n);
+int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, float* out2, void* workspace, size_t workspace_bytes,
+                        void* stream);
+/* HF-style AdamW on a flat segment (mafed/optim/adamw.py:86-111): m,v update; denom = sqrt(v) + eps (not bias
+ * corrected); p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/denom; then p -= lr*wd*p.  g is multiplied by clip_scale_dev[1]
+ * (from mafed_gradnorm_clip) and by grad_mul (1/world for DDP means).  lr_dev: device scalar (scheduled lr).
+ * If p_bf16 != NULL also writes the bf16 shadow copy used by the MFMA GEMMs.  The host keeps decayed and
+ * non-decayed parameters in two contiguous segments of the flat buffer and calls this once per segment. */
+int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                     float eps, float weight_decay, int step, const float* clip_dev /* out2 of gradnorm or NULL */,
+                     float grad_mul, void* p_bf16, void* stream);
+
+/* ---- small utilities --------------------------------------------------------------------------------------------- */
+int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype dst_dtype, int64_t n, void* stream);
+/* y = gelu_erf(x) elementwise (used by tests; the product path fuses GELU into mafed_gemm) */
+int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream);
+
+/* test hook: the exact (non-MFMA) forward kernel on bf16 data -- on-GPU cross-check of the MFMA kernels */
+int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                              const int64_t* attention_mask, int T, void* out, float* lse, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAFED_HIP_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of the C-ABI library ``libmafed_hip.so`` (include/mafed_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmafed_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+
+_p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mafed_hip.h one to one
+SIGNATURES = {
+    "mafed_version": (_i, []),
+    "mafed_last_error_string": (C.c_char_p, []),
+    "mafed_gemm": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p]),
+    "mafed_colsum_workspace_bytes": (_z, [_l, _l]),
+    "mafed_colsum": (_i, [_p, _i, _l, _l, _l, _p, _p, _z, _p]),
+    "mafed_layernorm_fwd": (_i, [_p, _l, _i, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "mafed_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
+    "mafed_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _z, _p]),
+    "mafed_attn_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "mafed_attn_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "mafed_attn_fwd_exact_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "mafed_embed_concat_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _l, _p, _p]),
+    "mafed_embed_concat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _l, _p, _i, _p, _p]),
+    "mafed_ce_fwd": (_i, [_p, _i, _p, _i, _i, _l, _p, _p, _p, _p]),
+    "mafed_ce_bwd": (_i, [_p, _i, _p, _p, _i, _i, _l, _p, _p, _p]),
+    "mafed_distill_workspace_bytes": (_z, [_l]),
+    "mafed_distill_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "mafed_distill_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
+    "mafed_distill_cls_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "mafed_distill_cls_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "mafed_gradnorm_workspace_bytes": (_z, [_l]),
+    "mafed_gradnorm_clip": (_i, [_p, _l, _f, _p, _p, _z, _p]),
+    "mafed_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
+    "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
+    "mafed_gelu": (_i, [_p, _p, _i, _l, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class MafedHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every exported entry point; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MafedHipError(
+            f"{LIB_PATH} is missing: build it with `python -m mafed_amd.build` (or __graft_entry__.build()). "
+            "mafed_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mafed_last_error_string()
+        raise MafedHipError(f"{what or 'mafed call'} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,23 @@
+// Shared declarations of the attention kernels (exact-fp32 parity kernels + bf16 MFMA kernels).
+#pragma once
+#include "common.h"
+
+namespace mafed {
+
+struct AttnShape {
+  int B, S, H, D, rot, T, P;
+};
+
+template <typename T>
+int attn_ref_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
+                        hipStream_t st);
+template <typename T>
+int attn_ref_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
+                        const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st);
+
+int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
+                         hipStream_t st);
+int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
+                         const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st);
+
+}  // namespace mafed

@@ -1,0 +1,73 @@
+// C-ABI entry points of the attention path: argument validation + dispatch (bf16 -> MFMA kernels, f32 -> parity kernels).
+#include "attn.h"
+
+using namespace mafed;
+
+static int check_common(const char* who, const void* qkv, int B, int S, int H, int D, int rot, const float* rc, const float* rs,
+                        const int64_t* am, int T) {
+  MAFED_CHECK_ARG(qkv && am, "%s: null pointer", who);
+  MAFED_CHECK_ARG(B > 0 && S > 0 && H > 0 && D > 0 && T >= 0 && T <= S, "%s: bad shape B=%d S=%d H=%d D=%d T=%d", who, B, S, H, D, T);
+  MAFED_CHECK_ARG(rot >= 0 && rot <= D && rot % 2 == 0, "%s: rotary dims %d invalid for D=%d", who, rot, D);
+  MAFED_CHECK_ARG(rot == 0 || (rc && rs), "%s: rotary tables missing", who);
+  return MAFED_OK;
+}
+
+static bool mfma_ok(int D, int rot) { return (D == 64 || D == 128) && (rot == 0 || rot == 16 || rot == 32 || rot == 64) && rot * 2 <= D * 2; }
+
+extern "C" int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, int H, int D, int rot, const float* rot_cos,
+                              const float* rot_sin, const int64_t* attention_mask, int T, void* out, float* lse, void* stream) {
+  int rc = check_common("attn_fwd", qkv, B, S, H, D, rot, rot_cos, rot_sin, attention_mask, T);
+  if (rc) return rc;
+  MAFED_CHECK_ARG(out && lse, "attn_fwd: null output");
+  AttnShape sh{B, S, H, D, rot, T, S - T};
+  hipStream_t st = as_stream(stream);
+  if (dtype == MAFED_F32) {
+    MAFED_CHECK_ARG(D <= 256, "attn_fwd(f32): D=%d > 256", D);
+    rc = attn_ref_fwd_launch<float>(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, st);
+  } else if (mfma_ok(D, rot)) {
+    MAFED_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "attn_fwd(bf16): qkv/out must be 16-byte aligned");
+    rc = attn_mfma_fwd_launch(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, st);
+  } else {
+    MAFED_CHECK_ARG(D <= 256, "attn_fwd(bf16): D=%d > 256", D);
+    rc = attn_ref_fwd_launch<bf16_t>(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, st);  // head sizes without an MFMA kernel yet
+  }
+  if (rc) return rc;
+  MAFED_CHECK_LAUNCH("attn_fwd");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype, int B, int S, int H,
+                              int D, int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* dqkv,
+                              float* delta, void* stream) {
+  int rc = check_common("attn_bwd", qkv, B, S, H, D, rot, rot_cos, rot_sin, attention_mask, T);
+  if (rc) return rc;
+  MAFED_CHECK_ARG(out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
+  AttnShape sh{B, S, H, D, rot, T, S - T};
+  hipStream_t st = as_stream(stream);
+  if (dtype == MAFED_F32) {
+    MAFED_CHECK_ARG(D <= 256, "attn_bwd(f32): D=%d > 256", D);
+    rc = attn_ref_bwd_launch<float>(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, st);
+  } else if (mfma_ok(D, rot)) {
+    MAFED_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0,
+                    "attn_bwd(bf16): tensors must be 16-byte aligned");
+    rc = attn_mfma_bwd_launch(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, st);
+  } else {
+    MAFED_CHECK_ARG(D <= 256, "attn_bwd(bf16): D=%d > 256", D);
+    rc = attn_ref_bwd_launch<bf16_t>(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, st);
+  }
+  if (rc) return rc;
+  MAFED_CHECK_LAUNCH("attn_bwd");
+  return MAFED_OK;
+}
+
+// test hook: run the exact kernels on bf16 data (on-GPU cross-check of the MFMA kernels)
+extern "C" int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                                         const int64_t* attention_mask, int T, void* out, float* lse, void* stream) {
+  int rc = check_common("attn_fwd_exact_bf16", qkv, B, S, H, D, rot, rot_cos, rot_sin, attention_mask, T);
+  if (rc) return rc;
+  AttnShape sh{B, S, H, D, rot, T, S - T};
+  rc = attn_ref_fwd_launch<bf16_t>(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, as_stream(stream));
+  if (rc) return rc;
+  MAFED_CHECK_LAUNCH("attn_fwd_exact_bf16");
+  return MAFED_OK;
+}

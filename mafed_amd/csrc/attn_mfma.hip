@@ -1,0 +1,465 @@
+// bf16 MFMA flash-style attention for the VLPythia decoder (tf:154-236; replaces the flash-attn-2 wheel, README.md:16).
+//
+// Orientation: every product is computed with the QUERY (forward, dQ) or the KEY (dK/dV) on MFMA column = lane&15, so
+// that row statistics (running max / sum, LSE, delta) are lane-local scalars, the S^T / dS^T accumulators are already
+// the B operand of the next product (cdna_hip_programming "An accumulator tile as the next MFMA's operand"), and the
+// output accumulators hold 4 consecutive head-dim elements per lane (8-byte stores).  The operand that must be read
+// along its row index (V and K for O / dQ; dO and Q for dV / dK) comes from the same row-major LDS image through the
+// gfx950 transposing read ds_read_b64_tr_b16 -- no transposed copies in LDS or HBM.
+// Partial rotary is applied while q / k rows are staged (on load), its transpose while dq / dk are stored.
+// Masking: fully causal over S = P + T, key padding from attention_mask (left-padded text); only tiles that touch the
+// diagonal or the text range pay for the mask.
+#include "attn.h"
+
+namespace mafed {
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+// [rows][D] bf16 image, 16-byte chunk swizzle (row reads with ds_read_b128 and transposing reads share it)
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  if (D == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 r;
+  r.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+  r.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+  r.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+  r.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+  return r;
+}
+
+// One 16-byte chunk (8 head-dim elements starting at chunk*8) of row `pos` of a q or k matrix, rotated (tf:111-151).
+// rowp points at element 0 of that row; rows >= S give zeros.
+__device__ __forceinline__ uint4 load_chunk_rot(const bf16_t* __restrict__ rowp, int chunk, int rot, const float* __restrict__ rc,
+                                                const float* __restrict__ rs, int pos, bool valid) {
+  if (!valid) return make_uint4(0u, 0u, 0u, 0u);
+  const uint4 x = *reinterpret_cast<const uint4*>(rowp + chunk * 8);
+  if (chunk * 8 >= rot) return x;
+  const int hc = rot >> 4;  // chunks per rotary half
+  const uint4 y = *reinterpret_cast<const uint4*>(rowp + (chunk ^ hc) * 8);
+  const bool first = chunk < hc;
+  const int d0 = (first ? chunk : chunk - hc) * 8;
+  const float* c = rc + (int64_t)pos * (rot >> 1) + d0;
+  const float* s = rs + (int64_t)pos * (rot >> 1) + d0;
+  float xf[8], yf[8], o[8];
+  unpack8(x, xf);
+  unpack8(y, yf);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = first ? (xf[e] * c[e] - yf[e] * s[e]) : (xf[e] * c[e] + yf[e] * s[e]);
+  return pack8(o);
+}
+
+// Stage `NROWS` rows (global rows r0 .. r0+NROWS-1 of one (b,h) matrix, element stride rstride) into an LDS image.
+template <int D, int NROWS, bool ROT>
+__device__ __forceinline__ void stage_rows(char* __restrict__ img, const bf16_t* __restrict__ base, int64_t rstride, int r0, int S, int rot,
+                                           const float* __restrict__ rc, const float* __restrict__ rs, int tid) {
+  constexpr int CPR = D / 8;  // chunks per row
+#pragma unroll
+  for (int c = tid; c < NROWS * CPR; c += 256) {
+    const int row = c / CPR, ch = c % CPR;
+    const int gr = r0 + row;
+    uint4 v;
+    if (ROT) v = load_chunk_rot(base + (int64_t)gr * rstride, ch, rot, rc, rs, gr, gr < S);
+    else v = gr < S ? *reinterpret_cast<const uint4*>(base + (int64_t)gr * rstride + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(img + tile_off<D>(row, ch)) = v;
+  }
+}
+
+// row-read fragment: lane gets X[row = rt*16 + (lane&15)][d = ks*32 + 8*(lane>>4) + e], e = 0..7
+template <int D>
+__device__ __forceinline__ bf16x8 frag_row(const char* __restrict__ img, int rt, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(img + tile_off<D>(rt * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+}
+// transposed fragment for the k-step kk (32 rows): lane (i = lane&15, g = lane>>4) gets X[row(g,e)][d = dt*16 + i] with
+// row(g,e) = kk*32 + 4g + e (e < 4) or kk*32 + 16 + 4g + (e-4): the k order in which accumulator tiles 2kk, 2kk+1 pack.
+template <int D>
+__device__ __forceinline__ bf16x8 frag_tr(const char* __restrict__ img, int dt, int kk, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int r_lo = kk * 32 + 4 * g + q, r_hi = r_lo + 16;
+  const int ch = 2 * dt + (p >> 1), sub = (p & 1) * 8;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + tile_off<D>(r_lo, ch) + sub));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + tile_off<D>(r_hi, ch) + sub));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return r;
+}
+
+// column-operand fragment straight from global: lane gets X[row0 + (lane&15)][d = ks*32 + 8*(lane>>4) + e] (rotated if ROT)
+template <int D, bool ROT>
+__device__ __forceinline__ void load_col_frags(bf16x8 (&f)[D / 32], const bf16_t* __restrict__ base, int64_t rstride, int row0, int S, int rot,
+                                               const float* __restrict__ rc, const float* __restrict__ rs, int lane) {
+  const int r = row0 + (lane & 15);
+#pragma unroll
+  for (int ks = 0; ks < D / 32; ++ks) {
+    const int ch = ks * 4 + (lane >> 4);
+    uint4 v;
+    if (ROT) v = load_chunk_rot(base + (int64_t)r * rstride, ch, rot, rc, rs, r, r < S);
+    else v = r < S ? *reinterpret_cast<const uint4*>(base + (int64_t)r * rstride + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+    f[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// reduce over the four lanes that share lane&15 (the 4 row groups of an accumulator column)
+__device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// store 4 consecutive head-dim elements after undoing the rotary (gradient rows).  acc[dt] holds d = dt*16 + 4g + r.
+template <int D>
+__device__ __forceinline__ void store_grad_unrot(bf16_t* __restrict__ rowp, f32x4 (&acc)[D / 16], int rot, const float* __restrict__ rc,
+                                                 const float* __restrict__ rs, int pos, int lane, bool valid) {
+  const int g = lane >> 4;
+  const int half = rot >> 1;
+  if (rot == 16) {
+    // d = 4g + r in tile 0: g in {0,1} first half, g in {2,3} second half; partner is lane ^ 32
+    f32x4 mine = acc[0], other;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(mine[r], 32, 64);
+    if (valid) {
+      const bool first = g < 2;
+      const int d0 = (first ? 4 * g : 4 * g - 8);
+      const float* c = rc + (int64_t)pos * half + d0;
+      const float* s = rs + (int64_t)pos * half + d0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[0][r] = first ? (mine[r] * c[r] + other[r] * s[r]) : (mine[r] * c[r] - other[r] * s[r]);
+    }
+  } else if (rot >= 32) {
+    // half >= 16: partner tile dt + half/16, same lane
+    const int ht = half >> 4;
+    if (valid) {
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        if (dt < ht) {
+          const int d0 = dt * 16 + 4 * g;
+          const float* c = rc + (int64_t)pos * half + d0;
+          const float* s = rs + (int64_t)pos * half + d0;
+          if (dt + ht < D / 16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = acc[dt][r], b = acc[dt + ht][r];
+              acc[dt][r] = a * c[r] + b * s[r];
+              acc[dt + ht][r] = b * c[r] - a * s[r];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt)
+      store4(rowp + dt * 16 + 4 * g, make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]));
+  }
+}
+
+__device__ __forceinline__ bool key_ok(const int64_t* __restrict__ am, int b, int key, int P, int T, int S) {
+  return key < P || (key < S && am[(int64_t)b * T + (key - P)] != 0);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// forward: block = 64 query rows of one (b,h), 4 waves x 16 rows; loop over 64-key tiles up to the diagonal
+// ------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
+                                                            const float* __restrict__ rs, const int64_t* __restrict__ am,
+                                                            bf16_t* __restrict__ out, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
+  char* kimg = lds;
+  char* vimg = lds + 64 * D * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
+  // heaviest (last) query tiles first: they have the most key tiles
+  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const bf16_t* kb = qb + D;
+  const bf16_t* vb = qb + 2 * D;
+  const int q0 = qt * 64 + wave * 16;
+  const int myq = q0 + (lane & 15);
+  const int g = lane >> 4;
+
+  bf16x8 qf[D / 32];
+  load_col_frags<D, true>(qf, qb, rstride, q0, S, rot, rc, rs, lane);
+
+  f32x4 o[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const float scale = rsqrtf((float)D);
+
+  for (int kt = 0; kt <= qt; ++kt) {
+    __syncthreads();
+    stage_rows<D, 64, true>(kimg, kb, rstride, kt * 64, S, rot, rc, rs, tid);
+    stage_rows<D, 64, false>(vimg, vb, rstride, kt * 64, S, rot, rc, rs, tid);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < D / 32; ++ks) s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, j, ks, lane), qf[ks], s[j], 0, 0, 0);
+    }
+    const bool need_mask = (kt == qt) || (kt * 64 + 63 >= P);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[j][r] * scale;
+        if (need_mask) {
+          const int key = kt * 64 + j * 16 + 4 * g + r;
+          if (key > myq || !key_ok(am, b, key, P, T, S)) v = -INFINITY;
+        }
+        s[j][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = col_max(tmax);
+    const float mn = fmaxf(m, tmax);
+    const float alpha = __expf(m - mn);  // m = -inf on the first tile -> 0
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[j][r] - mn);
+        s[j][r] = p;
+        ps += p;
+      }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) o[i] *= alpha;
+    const bf16x8 p0 = pack_acc(s[0], s[1]), p1 = pack_acc(s[2], s[3]);
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, 0, lane), p0, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, 1, lane), p1, o[dt], 0, 0, 0);
+    }
+  }
+  l = col_sum(l);
+  if (myq < S) {
+    const float inv = 1.0f / l;
+    bf16_t* op = out + ((int64_t)b * S + myq) * H * D + (int64_t)h * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt)
+      store4(op + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
+    if (g == 0) lse[((int64_t)b * H + h) * S + myq] = m + logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, query-owned: delta = rowsum(dO * O) and dQ
+// ------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse, AttnShape sh,
+                                                               const float* __restrict__ rc, const float* __restrict__ rs,
+                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
+                                                               float* __restrict__ delta) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
+  char* kimg = lds;
+  char* vimg = lds + 64 * D * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
+  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const bf16_t* kb = qb + D;
+  const bf16_t* vb = qb + 2 * D;
+  const int q0 = qt * 64 + wave * 16;
+  const int myq = q0 + (lane & 15);
+  const int g = lane >> 4;
+  const int64_t ostride = (int64_t)H * D;
+  const bf16_t* ob = out + (int64_t)b * S * ostride + (int64_t)h * D;
+  const bf16_t* dob = dout + (int64_t)b * S * ostride + (int64_t)h * D;
+
+  bf16x8 qf[D / 32], dof[D / 32];
+  load_col_frags<D, true>(qf, qb, rstride, q0, S, rot, rc, rs, lane);
+  load_col_frags<D, false>(dof, dob, ostride, q0, S, 0, rc, rs, lane);
+  float dl = 0.f;
+  {
+    bf16x8 of[D / 32];
+    load_col_frags<D, false>(of, ob, ostride, q0, S, 0, rc, rs, lane);
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[ks][e];
+    dl = col_sum(dl);
+  }
+  float L = 0.f;
+  if (myq < S) {
+    L = lse[((int64_t)b * H + h) * S + myq];
+    if (g == 0) delta[((int64_t)b * H + h) * S + myq] = dl;
+  }
+  f32x4 dq[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float scale = rsqrtf((float)D);
+
+  for (int kt = 0; kt <= qt; ++kt) {
+    __syncthreads();
+    stage_rows<D, 64, true>(kimg, kb, rstride, kt * 64, S, rot, rc, rs, tid);
+    stage_rows<D, 64, false>(vimg, vb, rstride, kt * 64, S, rot, rc, rs, tid);
+    __syncthreads();
+    const bool need_mask = (kt == qt) || (kt * 64 + 63 >= P);
+    f32x4 ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < D / 32; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, j, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(vimg, j, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __expf(s[r] * scale - L);
+        if (need_mask) {
+          const int key = kt * 64 + j * 16 + 4 * g + r;
+          if (key > myq || !key_ok(am, b, key, P, T, S)) p = 0.f;
+        }
+        ds[j][r] = p * (dp[r] - dl) * scale;
+      }
+    }
+    const bf16x8 d0 = pack_acc(ds[0], ds[1]), d1 = pack_acc(ds[2], ds[3]);
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, 0, lane), d0, dq[dt], 0, 0, 0);
+      dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, 1, lane), d1, dq[dt], 0, 0, 0);
+    }
+  }
+  bf16_t* dqp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)myq * rstride;
+  store_grad_unrot<D>(dqp, dq, rot, rc, rs, myq, lane, myq < S);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, key-owned: dK and dV of 64 keys (16 per wave); loop over the query tiles at or below the diagonal
+// ------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta, AttnShape sh,
+                                                                const float* __restrict__ rc, const float* __restrict__ rs,
+                                                                const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2 + 2 * 64 * 4];
+  char* qimg = lds;
+  char* doimg = lds + 64 * D * 2;
+  float* Ls = reinterpret_cast<float*>(lds + 2 * 64 * D * 2);
+  float* dls = Ls + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;  // low key tiles (most query tiles) are dispatched first
+  const int nqt = (S + 63) / 64;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const bf16_t* kb = qb + D;
+  const bf16_t* vb = qb + 2 * D;
+  const int64_t ostride = (int64_t)H * D;
+  const bf16_t* dob = dout + (int64_t)b * S * ostride + (int64_t)h * D;
+  const int k0 = kt * 64 + wave * 16;
+  const int mykey = k0 + (lane & 15);
+  const int g = lane >> 4;
+  const bool mykey_ok = key_ok(am, b, mykey, P, T, S);
+
+  bf16x8 kf[D / 32], vf[D / 32];
+  load_col_frags<D, true>(kf, kb, rstride, k0, S, rot, rc, rs, lane);
+  load_col_frags<D, false>(vf, vb, rstride, k0, S, 0, rc, rs, lane);
+  f32x4 dk[D / 16], dv[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float scale = rsqrtf((float)D);
+  const int64_t lbase = ((int64_t)b * H + h) * S;
+
+  for (int qt = kt; qt < nqt; ++qt) {
+    __syncthreads();
+    stage_rows<D, 64, true>(qimg, qb, rstride, qt * 64, S, rot, rc, rs, tid);
+    stage_rows<D, 64, false>(doimg, dob, ostride, qt * 64, S, 0, rc, rs, tid);
+    if (tid < 64) {
+      const int q = qt * 64 + tid;
+      Ls[tid] = q < S ? lse[lbase + q] : 0.f;
+      dls[tid] = q < S ? delta[lbase + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 p[4], ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < D / 32; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(qimg, j, ks, lane), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(doimg, j, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      const float4 Lq = *reinterpret_cast<const float4*>(Ls + j * 16 + 4 * g);
+      const float4 Dq = *reinterpret_cast<const float4*>(dls + j * 16 + 4 * g);
+      const float La[4] = {Lq.x, Lq.y, Lq.z, Lq.w}, Da[4] = {Dq.x, Dq.y, Dq.z, Dq.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = qt * 64 + j * 16 + 4 * g + r;
+        float pv = __expf(s[r] * scale - La[r]);
+        if (!mykey_ok || mykey > q || q >= S) pv = 0.f;
+        p[j][r] = pv;
+        ds[j][r] = pv * (dp[r] - Da[r]) * scale;
+      }
+    }
+    const bf16x8 p0 = pack_acc(p[0], p[1]), p1 = pack_acc(p[2], p[3]);
+    const bf16x8 d0 = pack_acc(ds[0], ds[1]), d1 = pack_acc(ds[2], ds[3]);
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, 0, lane), p0, dv[dt], 0, 0, 0);
+      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, 1, lane), p1, dv[dt], 0, 0, 0);
+      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, 0, lane), d0, dk[dt], 0, 0, 0);
+      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, 1, lane), d1, dk[dt], 0, 0, 0);
+    }
+  }
+  bf16_t* dkp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)mykey * rstride + D;
+  store_grad_unrot<D>(dkp, dk, rot, rc, rs, mykey, lane, mykey < S);
+  if (mykey < S) {
+    bf16_t* dvp = dkp + D;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) store4(dvp + dt * 16 + 4 * g, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
+  }
+}
+
+int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
+                         hipStream_t st) {
+  dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
+  if (sh.D == 64) attn_fwd_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+  else attn_fwd_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+  return MAFED_OK;
+}
+
+int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
+                         const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st) {
+  dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
+  if (sh.D == 64) {
+    attn_bwd_dq_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
+                                                        (bf16_t*)dqkv, delta);
+    attn_bwd_dkv_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
+  } else {
+    attn_bwd_dq_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
+                                                         (bf16_t*)dqkv, delta);
+    attn_bwd_dkv_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
+  }
+  return MAFED_OK;
+}
+
+}  // namespace mafed

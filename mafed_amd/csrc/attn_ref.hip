@@ -1,0 +1,235 @@
+// Exact-fp32 attention kernels (parity mode of the north star's 1e-3 gate, any head size <= 256, and the on-GPU
+// cross-check of the MFMA kernels).  One wave per query row (forward / dQ) or per key row (dK, dV); scores are
+// lane-parallel over the other sequence index, outputs lane-parallel over the head dimension.
+// Semantics: GPTNeoXAttention eager path (tf:154-236): partial rotary on q,k; scale D^-0.5; mask = causal AND
+// key-padding; softmax in fp32; fully causal over the whole [image | text] sequence.
+#include "attn.h"
+
+namespace mafed {
+
+// element d of the rotated row (tf:111-151): first `rot` dims rotate with the NeoX half pairing d <-> d +- rot/2
+template <typename T>
+__device__ __forceinline__ float rot_elem(const T* __restrict__ row, int d, int rot, const float* __restrict__ c, const float* __restrict__ s) {
+  const float x = Elem<T>::load(row + d);
+  if (d >= rot) return x;
+  const int half = rot >> 1;
+  if (d < half) return x * c[d] - Elem<T>::load(row + d + half) * s[d];
+  return x * c[d - half] + Elem<T>::load(row + d - half) * s[d - half];
+}
+// transpose of the rotation applied to a gradient row g (indexed through LDS)
+__device__ __forceinline__ float unrot_elem(const float* __restrict__ g, int d, int rot, const float* __restrict__ c, const float* __restrict__ s) {
+  const float x = g[d];
+  if (d >= rot) return x;
+  const int half = rot >> 1;
+  if (d < half) return x * c[d] + g[d + half] * s[d];
+  return x * c[d - half] - g[d - half] * s[d - half];
+}
+
+__device__ __forceinline__ bool key_valid(const int64_t* __restrict__ am, int b, int j, int P, int T) {
+  return j < P || am[(int64_t)b * T + (j - P)] != 0;
+}
+
+// LDS per wave: qrow[D] + sc[S] floats
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ref_fwd_kernel(const T* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
+                                                           const float* __restrict__ rs, const int64_t* __restrict__ am,
+                                                           T* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = sh.S, H = sh.H, D = sh.D, rot = sh.rot, half = sh.rot >> 1;
+  const int q = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+  float* qrow = lds + (size_t)wave * (D + S);
+  float* sc = qrow + D;
+  if (q >= S) return;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const T* base = qkv + ((int64_t)b * S * H + h) * 3 * D;  // + s * rstride + {0,D,2D}
+  const T* qp = base + (int64_t)q * rstride;
+  for (int d = lane; d < D; d += 64) qrow[d] = rot_elem(qp, d, rot, rc + (int64_t)q * half, rs + (int64_t)q * half);
+  __builtin_amdgcn_wave_barrier();
+  const float scale = rsqrtf((float)D);
+  float m = -INFINITY;
+  for (int j = lane; j <= q; j += 64) {
+    float s = -INFINITY;
+    if (key_valid(am, b, j, sh.P, sh.T)) {
+      const T* kp = base + (int64_t)j * rstride + D;
+      float acc = 0.f;
+      for (int d = 0; d < D; ++d) acc = fmaf(qrow[d], rot_elem(kp, d, rot, rc + (int64_t)j * half, rs + (int64_t)j * half), acc);
+      s = acc * scale;
+    }
+    sc[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j <= q; j += 64) {
+    const float p = expf(sc[j] - m);
+    sc[j] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  __builtin_amdgcn_wave_barrier();
+  const float inv = 1.0f / l;
+  T* op = out + ((int64_t)b * S + q) * H * D + (int64_t)h * D;
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j <= q; ++j) acc = fmaf(sc[j], Elem<T>::load(base + (int64_t)j * rstride + 2 * D + d), acc);
+    Elem<T>::store(op + d, acc * inv);
+  }
+  if (lane == 0) lse[((int64_t)b * H + h) * S + q] = m + logf(l);
+}
+
+// dQ (+ delta): one wave per query row.  LDS per wave: qrow[D] + dorow[D] + gq[D] + sc[S]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ref_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
+                                                              const float* __restrict__ lse, AttnShape sh, const float* __restrict__ rc,
+                                                              const float* __restrict__ rs, const int64_t* __restrict__ am,
+                                                              T* __restrict__ dqkv, float* __restrict__ delta) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = sh.S, H = sh.H, D = sh.D, rot = sh.rot, half = sh.rot >> 1;
+  const int q = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+  float* qrow = lds + (size_t)wave * (3 * D + S);
+  float* dorow = qrow + D;
+  float* gq = dorow + D;
+  float* sc = gq + D;
+  if (q >= S) return;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const T* base = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const T* qp = base + (int64_t)q * rstride;
+  const T* op = out + ((int64_t)b * S + q) * H * D + (int64_t)h * D;
+  const T* dop = dout + ((int64_t)b * S + q) * H * D + (int64_t)h * D;
+  float dl = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    qrow[d] = rot_elem(qp, d, rot, rc + (int64_t)q * half, rs + (int64_t)q * half);
+    const float g = Elem<T>::load(dop + d);
+    dorow[d] = g;
+    dl += g * Elem<T>::load(op + d);
+  }
+  dl = wave_sum(dl);
+  if (lane == 0) delta[((int64_t)b * H + h) * S + q] = dl;
+  __builtin_amdgcn_wave_barrier();
+  const float scale = rsqrtf((float)D);
+  const float L = lse[((int64_t)b * H + h) * S + q];
+  for (int j = lane; j <= q; j += 64) {
+    float ds = 0.f;
+    if (key_valid(am, b, j, sh.P, sh.T)) {
+      const T* kp = base + (int64_t)j * rstride + D;
+      const T* vp = kp + D;
+      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < D; ++d) {
+        s = fmaf(qrow[d], rot_elem(kp, d, rot, rc + (int64_t)j * half, rs + (int64_t)j * half), s);
+        dp = fmaf(dorow[d], Elem<T>::load(vp + d), dp);
+      }
+      const float p = expf(s * scale - L);
+      ds = p * (dp - dl) * scale;
+    }
+    sc[j] = ds;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j <= q; ++j) {
+      const T* kp = base + (int64_t)j * rstride + D;
+      acc = fmaf(sc[j], rot_elem(kp, d, rot, rc + (int64_t)j * half, rs + (int64_t)j * half), acc);
+    }
+    gq[d] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  T* dqp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)q * rstride;
+  for (int d = lane; d < D; d += 64) Elem<T>::store(dqp + d, unrot_elem(gq, d, rot, rc + (int64_t)q * half, rs + (int64_t)q * half));
+}
+
+// dK, dV: one wave per key row j; queries q >= j.  LDS per wave: krow[D] + vrow[D] + gk[D] + pq[S] + dsq[S]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ref_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               AttnShape sh, const float* __restrict__ rc, const float* __restrict__ rs,
+                                                               const int64_t* __restrict__ am, T* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = sh.S, H = sh.H, D = sh.D, rot = sh.rot, half = sh.rot >> 1;
+  const int j = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+  float* krow = lds + (size_t)wave * (3 * D + 2 * S);
+  float* vrow = krow + D;
+  float* gk = vrow + D;
+  float* pq = gk + D;
+  float* dsq = pq + S;
+  if (j >= S) return;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const T* base = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  T* dkp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)j * rstride + D;
+  T* dvp = dkp + D;
+  if (!key_valid(am, b, j, sh.P, sh.T)) {  // masked key: no query attends to it
+    for (int d = lane; d < D; d += 64) { Elem<T>::store(dkp + d, 0.f); Elem<T>::store(dvp + d, 0.f); }
+    return;
+  }
+  const T* kp = base + (int64_t)j * rstride + D;
+  for (int d = lane; d < D; d += 64) {
+    krow[d] = rot_elem(kp, d, rot, rc + (int64_t)j * half, rs + (int64_t)j * half);
+    vrow[d] = Elem<T>::load(kp + D + d);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float scale = rsqrtf((float)D);
+  for (int q = j + lane; q < S; q += 64) {
+    const T* qp = base + (int64_t)q * rstride;
+    const T* dop = dout + ((int64_t)b * S + q) * H * D + (int64_t)h * D;
+    float s = 0.f, dp = 0.f;
+    for (int d = 0; d < D; ++d) {
+      s = fmaf(rot_elem(qp, d, rot, rc + (int64_t)q * half, rs + (int64_t)q * half), krow[d], s);
+      dp = fmaf(Elem<T>::load(dop + d), vrow[d], dp);
+    }
+    const int64_t li = ((int64_t)b * H + h) * S + q;
+    const float p = expf(s * scale - lse[li]);
+    pq[q] = p;
+    dsq[q] = p * (dp - delta[li]) * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < D; d += 64) {
+    float av = 0.f, ak = 0.f;
+    for (int q = j; q < S; ++q) {
+      const T* qp = base + (int64_t)q * rstride;
+      const T* dop = dout + ((int64_t)b * S + q) * H * D + (int64_t)h * D;
+      av = fmaf(pq[q], Elem<T>::load(dop + d), av);
+      ak = fmaf(dsq[q], rot_elem(qp, d, rot, rc + (int64_t)q * half, rs + (int64_t)q * half), ak);
+    }
+    Elem<T>::store(dvp + d, av);
+    gk[d] = ak;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < D; d += 64) Elem<T>::store(dkp + d, unrot_elem(gk, d, rot, rc + (int64_t)j * half, rs + (int64_t)j * half));
+}
+
+template <typename T>
+int attn_ref_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
+                        hipStream_t st) {
+  const size_t lds = (size_t)4 * (sh.D + sh.S) * sizeof(float);
+  if (lds > 160 * 1024) { set_error("attn_fwd(f32): S=%d too long for the parity kernel", sh.S); return MAFED_EINVAL; }
+  auto k = attn_ref_fwd_kernel<T>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k<<<dim3((sh.S + 3) / 4, sh.H, sh.B), dim3(256), lds, st>>>((const T*)qkv, sh, rc, rs, am, (T*)out, lse);
+  return MAFED_OK;
+}
+
+template <typename T>
+int attn_ref_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
+                        const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st) {
+  const size_t lds1 = (size_t)4 * (3 * sh.D + sh.S) * sizeof(float), lds2 = (size_t)4 * (3 * sh.D + 2 * sh.S) * sizeof(float);
+  if (lds2 > 160 * 1024) { set_error("attn_bwd(f32): S=%d too long for the parity kernel", sh.S); return MAFED_EINVAL; }
+  auto k1 = attn_ref_bwd_dq_kernel<T>;
+  auto k2 = attn_ref_bwd_dkv_kernel<T>;
+  if (lds1 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  dim3 grid((sh.S + 3) / 4, sh.H, sh.B), block(256);
+  k1<<<grid, block, lds1, st>>>((const T*)qkv, (const T*)out, (const T*)dout, lse, sh, rc, rs, am, (T*)dqkv, delta);
+  k2<<<grid, block, lds2, st>>>((const T*)qkv, (const T*)dout, lse, delta, sh, rc, rs, am, (T*)dqkv);
+  return MAFED_OK;
+}
+
+template int attn_ref_fwd_launch<float>(const void*, const AttnShape&, const float*, const float*, const int64_t*, void*, float*, hipStream_t);
+template int attn_ref_fwd_launch<bf16_t>(const void*, const AttnShape&, const float*, const float*, const int64_t*, void*, float*, hipStream_t);
+template int attn_ref_bwd_launch<float>(const void*, const void*, const void*, const float*, const AttnShape&, const float*, const float*,
+                                        const int64_t*, void*, float*, hipStream_t);
+template int attn_ref_bwd_launch<bf16_t>(const void*, const void*, const void*, const float*, const AttnShape&, const float*, const float*,
+                                         const int64_t*, void*, float*, hipStream_t);
+
+}  // namespace mafed

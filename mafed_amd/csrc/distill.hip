@@ -1,0 +1,223 @@
+// MAFED modality-aware feature distillation (mafed/methods/distillation.py:124-166, 226-257).
+// One pass over the student/teacher hidden states of a layer serves BOTH modality masks: each token row is
+// classified from its position (image prefix / valid text / left pad) and its per-row distance is added to that
+// class's sum.  HBM-bound: 2 * rows * h * 4 B algorithmic read per layer; one wave per row, 16-byte loads;
+// deterministic two-stage reduction (per-block partials -> one finishing block), no float atomics.
+#include "common.h"
+
+namespace mafed {
+
+constexpr int DS_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ void row_stats(const float* __restrict__ s, const float* __restrict__ t, int h, int lane, float& dd,
+                                          float& ss, float& tt, float& st) {
+  dd = ss = tt = st = 0.f;
+  for (int c = lane * 4; c < h; c += 256) {
+    const float4 a = load4(s + c), b = load4(t + c);
+    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+    dd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    ss += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    tt += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+    st += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  }
+}
+
+// torch cosine_embedding_loss(target=1): 1 - st / sqrt((ss + eps) * (tt + eps)), eps = 1e-12 (aten EPSILON)
+__device__ __forceinline__ float cos_dist(float ss, float tt, float st) {
+  const float EPS = 1e-12f;
+  return 1.0f - st / sqrtf((ss + EPS) * (tt + EPS));
+}
+
+template <bool COSINE>
+__global__ __launch_bounds__(256) void distill_fwd_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                          const int64_t* __restrict__ attention_mask, int64_t rows, int S, int P,
+                                                          int T, int h, float* __restrict__ partial) {
+  __shared__ float sm[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // lang_sum, vision_sum, n_lang, n_vision
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int cls = modality_class(row, S, P, T, attention_mask);
+    if (cls == 2) continue;
+    float dd, ss, tt, st;
+    row_stats(s + row * h, t + row * h, h, lane, dd, ss, tt, st);
+    float d;
+    if (COSINE) {
+      ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+      d = cos_dist(ss, tt, st);
+    } else {
+      d = wave_sum(dd) / (float)h;
+    }
+    acc[cls] += d;
+    acc[2 + cls] += 1.f;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
+      (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void distill_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out4) {
+  __shared__ float sm[4];
+  for (int k = 0; k < 4; ++k) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * 4 + k];
+    s = block_sum<256>(s, sm);
+    if (threadIdx.x == 0) out4[k] = s;
+  }
+}
+
+template <bool COSINE>
+__global__ __launch_bounds__(256) void distill_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                          const int64_t* __restrict__ attention_mask, int64_t rows, int S, int P,
+                                                          int T, int h, const float* __restrict__ coef, float* __restrict__ ds,
+                                                          int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int cls = modality_class(row, S, P, T, attention_mask);
+  const float c = cls == 2 ? 0.f : coef[cls];
+  const float* sr = s + row * h;
+  const float* tr = t + row * h;
+  float* dr = ds + row * h;
+  if (c == 0.f) {
+    if (!accumulate)
+      for (int k = lane * 4; k < h; k += 256) store4(dr + k, make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  float a = 0.f, bq = 0.f;  // ds = a * t + bq * s   (cosine)   or   a * (s - t)   (mse)
+  if (COSINE) {
+    float dd, ss, tt, st;
+    row_stats(sr, tr, h, lane, dd, ss, tt, st);
+    ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+    const float EPS = 1e-12f;
+    const float denom = sqrtf((ss + EPS) * (tt + EPS));
+    // d/ds [1 - st/denom] = -( t/denom - st * (tt+eps) * s / denom^3 )
+    a = -c / denom;
+    bq = c * st * (tt + EPS) / (denom * denom * denom);
+  } else {
+    a = c * 2.0f / (float)h;
+  }
+  for (int k = lane * 4; k < h; k += 256) {
+    const float4 x = load4(sr + k), y = load4(tr + k);
+    float4 o;
+    if (COSINE) o = make_float4(a * y.x + bq * x.x, a * y.y + bq * x.y, a * y.z + bq * x.z, a * y.w + bq * x.w);
+    else o = make_float4(a * (x.x - y.x), a * (x.y - y.y), a * (x.z - y.z), a * (x.w - y.w));
+    if (accumulate) {
+      const float4 p = load4(dr + k);
+      o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    }
+    store4(dr + k, o);
+  }
+}
+
+// CLS variant: token 0 of every sample, cosine, mean over the batch.  B is small: one block, one wave per sample.
+__global__ __launch_bounds__(256) void distill_cls_fwd_kernel(const float* __restrict__ s, const float* __restrict__ t, int B, int S,
+                                                              int h, float* __restrict__ out1) {
+  __shared__ float sm[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = wave; b < B; b += 4) {
+    float dd, ss, tt, st;
+    row_stats(s + (int64_t)b * S * h, t + (int64_t)b * S * h, h, lane, dd, ss, tt, st);
+    ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+    acc += cos_dist(ss, tt, st);
+  }
+  if (lane == 0) sm[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out1[0] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)B;
+}
+
+__global__ __launch_bounds__(256) void distill_cls_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t, int B, int S,
+                                                              int h, const float* __restrict__ coef, float* __restrict__ ds,
+                                                              int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // over all B*S rows so that non-CLS rows get zeros when !accumulate
+  if (row >= (int64_t)B * S) return;
+  float* dr = ds + row * h;
+  if (row % S != 0) {
+    if (!accumulate)
+      for (int k = lane * 4; k < h; k += 256) store4(dr + k, make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  const float* sr = s + row * h;
+  const float* tr = t + row * h;
+  float dd, ss, tt, st;
+  row_stats(sr, tr, h, lane, dd, ss, tt, st);
+  ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+  const float EPS = 1e-12f, c = coef[0];
+  const float denom = sqrtf((ss + EPS) * (tt + EPS));
+  const float a = -c / denom, bq = c * st * (tt + EPS) / (denom * denom * denom);
+  for (int k = lane * 4; k < h; k += 256) {
+    const float4 x = load4(sr + k), y = load4(tr + k);
+    float4 o = make_float4(a * y.x + bq * x.x, a * y.y + bq * x.y, a * y.z + bq * x.z, a * y.w + bq * x.w);
+    if (accumulate) {
+      const float4 p = load4(dr + k);
+      o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    }
+    store4(dr + k, o);
+  }
+}
+
+static int ds_blocks(int64_t rows) {
+  int64_t nb = cdiv(rows, 4);
+  if (nb > DS_MAX_BLOCKS) nb = DS_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+}  // namespace mafed
+
+using namespace mafed;
+
+extern "C" size_t mafed_distill_workspace_bytes(int64_t rows) { return (size_t)ds_blocks(rows) * 4 * sizeof(float); }
+
+extern "C" int mafed_distill_fwd(const float* s, const float* t, const int64_t* attention_mask, int B, int S, int P, int h, int cosine,
+                                 float* out4, void* workspace, size_t workspace_bytes, void* stream) {
+  MAFED_CHECK_ARG(s && t && attention_mask && out4, "distill_fwd: null pointer");
+  MAFED_CHECK_ARG(B > 0 && S > 0 && P >= 0 && P <= S && h > 0 && h % 4 == 0, "distill_fwd: bad shape (h must be a multiple of 4)");
+  const int64_t rows = (int64_t)B * S;
+  const int nblk = ds_blocks(rows);
+  if (!workspace || workspace_bytes < (size_t)nblk * 4 * sizeof(float)) {
+    set_error("distill_fwd: workspace %zu < %zu", workspace_bytes, (size_t)nblk * 4 * sizeof(float));
+    return MAFED_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  if (cosine) distill_fwd_kernel<true><<<dim3(nblk), dim3(256), 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, (float*)workspace);
+  else distill_fwd_kernel<false><<<dim3(nblk), dim3(256), 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, (float*)workspace);
+  MAFED_CHECK_LAUNCH("distill_fwd");
+  distill_finish_kernel<<<dim3(1), dim3(256), 0, st>>>((const float*)workspace, nblk, out4);
+  MAFED_CHECK_LAUNCH("distill_fwd(finish)");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_distill_bwd(const float* s, const float* t, const int64_t* attention_mask, int B, int S, int P, int h, int cosine,
+                                 const float* coef_dev, float* ds, int accumulate, void* stream) {
+  MAFED_CHECK_ARG(s && t && attention_mask && coef_dev && ds, "distill_bwd: null pointer");
+  MAFED_CHECK_ARG(B > 0 && S > 0 && P >= 0 && P <= S && h > 0 && h % 4 == 0, "distill_bwd: bad shape (h must be a multiple of 4)");
+  const int64_t rows = (int64_t)B * S;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+  if (cosine) distill_bwd_kernel<true><<<grid, block, 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, coef_dev, ds, accumulate);
+  else distill_bwd_kernel<false><<<grid, block, 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, coef_dev, ds, accumulate);
+  MAFED_CHECK_LAUNCH("distill_bwd");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_distill_cls_fwd(const float* s, const float* t, int B, int S, int h, float* out1, void* stream) {
+  MAFED_CHECK_ARG(s && t && out1 && B > 0 && S > 0 && h > 0 && h % 4 == 0, "distill_cls_fwd: bad arguments");
+  distill_cls_fwd_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(s, t, B, S, h, out1);
+  MAFED_CHECK_LAUNCH("distill_cls_fwd");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_distill_cls_bwd(const float* s, const float* t, int B, int S, int h, const float* coef_dev, float* ds,
+                                     int accumulate, void* stream) {
+  MAFED_CHECK_ARG(s && t && coef_dev && ds && B > 0 && S > 0 && h > 0 && h % 4 == 0, "distill_cls_bwd: bad arguments");
+  const int64_t rows = (int64_t)B * S;
+  distill_cls_bwd_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, as_stream(stream)>>>(s, t, B, S, h, coef_dev, ds, accumulate);
+  MAFED_CHECK_LAUNCH("distill_cls_bwd");
+  return MAFED_OK;
+}

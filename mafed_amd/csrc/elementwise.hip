@@ -1,0 +1,186 @@
+// Small HBM-bound utilities: cast, GELU, embedding gather + image/text concat, column sums (bias gradients).
+#include "common.h"
+
+namespace mafed {
+
+template <typename SrcT, typename DstT>
+__global__ __launch_bounds__(256) void cast_kernel(const SrcT* __restrict__ src, DstT* __restrict__ dst, int64_t n4, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) store4(dst + i * 4, load4(src + i * 4));
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    Elem<DstT>::store(dst + i, Elem<SrcT>::load(src + i));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    Elem<T>::store(y + i, gelu_erf(Elem<T>::load(x + i)));
+}
+
+// h0[b,s,:] = s < P ? image[b,s,:] : embed_in[input_ids[b,s-P],:]     one wave per token row, 16-byte accesses
+template <typename ImgT>
+__global__ __launch_bounds__(256) void embed_concat_fwd_kernel(const ImgT* __restrict__ image, const float* __restrict__ embed_in,
+                                                               const int64_t* __restrict__ input_ids, int B, int P, int T, int h,
+                                                               int64_t V, float* __restrict__ h0) {
+  const int S = P + T;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * S) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = row / S;
+  const int s = (int)(row - b * S);
+  float* dst = h0 + row * h;
+  if (s < P) {
+    const ImgT* src = image + (b * P + s) * (int64_t)h;
+    for (int c = lane * 4; c < h; c += 256) store4(dst + c, load4(src + c));
+  } else {
+    int64_t id = input_ids[b * T + (s - P)];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float* src = embed_in + id * h;
+    for (int c = lane * 4; c < h; c += 256) store4(dst + c, load4(src + c));
+  }
+}
+
+template <typename ImgT>
+__global__ __launch_bounds__(256) void embed_concat_bwd_kernel(const float* __restrict__ dh0, const int64_t* __restrict__ input_ids,
+                                                               int B, int P, int T, int h, int64_t V, ImgT* __restrict__ d_image,
+                                                               float* __restrict__ d_embed_in) {
+  const int S = P + T;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * S) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = row / S;
+  const int s = (int)(row - b * S);
+  const float* src = dh0 + row * h;
+  if (s < P) {
+    if (d_image) {
+      ImgT* dst = d_image + (b * P + s) * (int64_t)h;
+      for (int c = lane * 4; c < h; c += 256) store4(dst + c, load4(src + c));
+    }
+  } else if (d_embed_in) {
+    int64_t id = input_ids[b * T + (s - P)];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    float* dst = d_embed_in + id * h;
+    // duplicate ids (pad id 0, repeated tokens) collide: fp32 atomics, contiguous 256 B per wave-instruction
+    for (int c = lane; c < h; c += 64) atomicAdd(dst + c, src[c]);
+  }
+}
+
+// stage 1: partial[blk][n] = sum over the block's row slice; stage 2 sums the partials and accumulates into out.
+constexpr int CS_ROWS = 64;  // rows per block slice (x 4 row-groups of threads)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx,
+                                                             float* __restrict__ partial) {
+  __shared__ float sm[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + col;
+  const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
+  float s = 0.f;
+  if (n < N) {
+    const int64_t m1 = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
+    for (int64_t m = m0 + grp; m < m1; m += 4) s += Elem<T>::load(X + m * ldx + n);
+  }
+  sm[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t nslice, int64_t N,
+                                                           float* __restrict__ out) {
+  __shared__ float sm[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (n < N)
+    for (int64_t b = grp; b < nslice; b += 4) s += partial[b * N + n];
+  sm[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && n < N) out[n] += (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
+}
+
+static int grid_for(int64_t n, int per_thread = 1) {
+  int64_t g = cdiv(n, 256 * (int64_t)per_thread);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace mafed
+
+using namespace mafed;
+
+extern "C" int mafed_cast(const void* src, mafed_dtype sd, void* dst, mafed_dtype dd, int64_t n, void* stream) {
+  MAFED_CHECK_ARG(src && dst && n >= 0, "cast: bad arguments");
+  if (n == 0) return MAFED_OK;
+  hipStream_t st = as_stream(stream);
+  const int64_t n4 = n / 4;
+  dim3 grid(grid_for(n4)), block(256);
+  if (sd == MAFED_F32 && dd == MAFED_BF16) cast_kernel<float, bf16_t><<<grid, block, 0, st>>>((const float*)src, (bf16_t*)dst, n4, n);
+  else if (sd == MAFED_BF16 && dd == MAFED_F32) cast_kernel<bf16_t, float><<<grid, block, 0, st>>>((const bf16_t*)src, (float*)dst, n4, n);
+  else if (sd == MAFED_F32 && dd == MAFED_F32) cast_kernel<float, float><<<grid, block, 0, st>>>((const float*)src, (float*)dst, n4, n);
+  else cast_kernel<bf16_t, bf16_t><<<grid, block, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n4, n);
+  MAFED_CHECK_LAUNCH("cast");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream) {
+  MAFED_CHECK_ARG(x && y && n >= 0, "gelu: bad arguments");
+  if (n == 0) return MAFED_OK;
+  hipStream_t st = as_stream(stream);
+  dim3 grid(grid_for(n)), block(256);
+  if (dtype == MAFED_F32) gelu_kernel<float><<<grid, block, 0, st>>>((const float*)x, (float*)y, n);
+  else gelu_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n);
+  MAFED_CHECK_LAUNCH("gelu");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_embed_concat_fwd(const void* image, mafed_dtype img_dtype, const float* embed_in, const int64_t* input_ids,
+                                      int B, int P, int T, int h, int64_t V, float* h0, void* stream) {
+  MAFED_CHECK_ARG(image && embed_in && input_ids && h0, "embed_concat_fwd: null pointer");
+  MAFED_CHECK_ARG(B >= 0 && P >= 0 && T >= 0 && h > 0 && h % 4 == 0 && V > 0, "embed_concat_fwd: bad shape (h must be a multiple of 4)");
+  const int64_t rows = (int64_t)B * (P + T);
+  if (rows == 0) return MAFED_OK;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+  if (img_dtype == MAFED_F32) embed_concat_fwd_kernel<float><<<grid, block, 0, st>>>((const float*)image, embed_in, input_ids, B, P, T, h, V, h0);
+  else embed_concat_fwd_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)image, embed_in, input_ids, B, P, T, h, V, h0);
+  MAFED_CHECK_LAUNCH("embed_concat_fwd");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_embed_concat_bwd(const float* dh0, const int64_t* input_ids, int B, int P, int T, int h, int64_t V,
+                                      void* d_image, mafed_dtype img_dtype, float* d_embed_in, void* stream) {
+  MAFED_CHECK_ARG(dh0 && input_ids, "embed_concat_bwd: null pointer");
+  MAFED_CHECK_ARG(B >= 0 && P >= 0 && T >= 0 && h > 0 && h % 4 == 0 && V > 0, "embed_concat_bwd: bad shape (h must be a multiple of 4)");
+  const int64_t rows = (int64_t)B * (P + T);
+  if (rows == 0) return MAFED_OK;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+  if (img_dtype == MAFED_F32) embed_concat_bwd_kernel<float><<<grid, block, 0, st>>>(dh0, input_ids, B, P, T, h, V, (float*)d_image, d_embed_in);
+  else embed_concat_bwd_kernel<bf16_t><<<grid, block, 0, st>>>(dh0, input_ids, B, P, T, h, V, (bf16_t*)d_image, d_embed_in);
+  MAFED_CHECK_LAUNCH("embed_concat_bwd");
+  return MAFED_OK;
+}
+
+extern "C" size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N) { return (size_t)cdiv(M, CS_ROWS) * (size_t)N * sizeof(float); }
+
+extern "C" int mafed_colsum(const void* X, mafed_dtype dtype, int64_t M, int64_t N, int64_t ldx, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  MAFED_CHECK_ARG(X && out && M >= 0 && N > 0 && ldx >= N, "colsum: bad arguments");
+  if (M == 0) return MAFED_OK;
+  const int64_t nslice = cdiv(M, CS_ROWS);
+  if (!workspace || workspace_bytes < (size_t)nslice * N * sizeof(float)) {
+    set_error("colsum: workspace %zu < %zu", workspace_bytes, (size_t)nslice * N * sizeof(float));
+    return MAFED_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)nslice), block(256);
+  if (dtype == MAFED_F32) colsum_partial_kernel<float><<<grid, block, 0, st>>>((const float*)X, M, N, ldx, (float*)workspace);
+  else colsum_partial_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)X, M, N, ldx, (float*)workspace);
+  MAFED_CHECK_LAUNCH("colsum(partial)");
+  colsum_final_kernel<<<dim3((unsigned)cdiv(N, 64)), block, 0, st>>>((const float*)workspace, nslice, N, out);
+  MAFED_CHECK_LAUNCH("colsum(final)");
+  return MAFED_OK;
+}

@@ -1,0 +1,275 @@
+// Dense contractions C = op(A).op(B) with fused epilogue.
+//
+//  bf16 path (the product path): v_mfma_f32_16x16x32_bf16, 128x128x64 block tile, 4 waves (2x2), each wave a 64x64
+//  sub-tile = 4x4 accumulators of 16x16.  Operands are staged global -> registers -> LDS (16-byte accesses,
+//  register prefetch of tile t+1 issued before the MFMAs of tile t, written after them: one barrier per K-tile,
+//  two LDS stages).  An operand whose reduction index is contiguous in memory ("KC": A of X.W^T, both of nothing
+//  else) is kept as [row][k] and read with ds_read_b128; an operand whose reduction index is the memory row
+//  ("KS": W in dX = dY.W, and BOTH operands of dW = dY^T.X) is kept as [k][row] and read with the gfx950 transposing
+//  read ds_read_b64_tr_b16, so no transposed copy of an activation or a weight is ever materialised in HBM.
+//  Both images are XOR-swizzled so that the fragment reads are bank-conflict free (see lds_off_*).
+//  The accumulator is computed transposed (mfma(Bfrag, Afrag)) so that each lane owns 4 CONSECUTIVE columns of one
+//  output row: 8/16-byte epilogue stores, float4 bias/residual loads.
+//
+//  fp32 path (parity mode, 1e-3 gate of the north star): plain FMA tile kernel, exact fp32 products.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace mafed {
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 parity kernel: 64x64 tile, BK = 16, 256 threads, 4x4 outputs per thread
+// ------------------------------------------------------------------------------------------------------------
+template <typename CT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                                       const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                       int64_t ldb, CT* __restrict__ C, GemmEpi epi) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int64_t k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (!transA) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+      const int64_t gm = m0 + m, gk = k0 + k;
+      float v = 0.f;
+      if (gm < M && gk < K) v = transA ? A[gk * lda + gm] : A[gm * lda + gk];
+      As[k][m] = v;
+      int n, kb;
+      if (transB) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+      const int64_t gn = n0 + n, gkb = k0 + kb;
+      float w = 0.f;
+      if (gn < N && gkb < K) w = transB ? B[gn * ldb + gkb] : B[gkb * ldb + gn];
+      Bs[kb][n] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + ty * 4 + i, n = n0 + tx * 4;
+    if (m < M && n < N) epilogue_store4<CT>(epi, C, m, n, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;              // one operand tile, either image: 16 KiB
+constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_BYTES;    // 2 stages x (A + B) = 64 KiB -> 2 blocks / CU
+
+// KC image: [128 rows][64 k] bf16, 128-byte rows, 16-byte chunk index XORed with (row>>1)&7:
+// a ds_read_b128 lane group (16 rows x one chunk, two rows per 256-byte bank row) then touches 16 distinct slots.
+__device__ __forceinline__ int lds_off_kc(int row, int kchunk) { return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4); }
+// KS image: [64 k][128 rows] bf16, 256-byte k-rows (= all 64 banks), 32-byte chunk (16 rows) index XORed with
+// f(k) = (k&3) | ((k>>3)&1)<<2: the 8 k-rows a 32-lane half reads in one ds_read_b64_tr_b16 get 8 distinct chunks.
+__device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int lds_off_ks(int k, int r16, int byte_in_32) { return k * 256 + ((r16 ^ ks_f(k)) << 5) + byte_in_32; }
+
+// global -> registers for one 128 x 64 operand tile (4 x 16 B per thread), zero-filled out of range
+template <bool KS>
+__device__ __forceinline__ void gemm_load_tile(const bf16_t* __restrict__ X, int64_t ld, int64_t r0, int64_t R, int64_t k0, int64_t K,
+                                               int tid, uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!KS) {
+      const int row = c >> 3, kc = c & 7;
+      const int64_t gr = r0 + row, gk = k0 + kc * 8;
+      if (gr < R && gk < K) v = *reinterpret_cast<const uint4*>(X + gr * ld + gk);  // K % 8 == 0
+    } else {
+      const int k = c >> 4, rc = c & 15;
+      const int64_t gk = k0 + k, gr = r0 + rc * 8;
+      if (gk < K && gr < R) v = *reinterpret_cast<const uint4*>(X + gk * ld + gr);  // R % 8 == 0
+    }
+    reg[i] = v;
+  }
+}
+
+template <bool KS>
+__device__ __forceinline__ void gemm_store_tile(char* __restrict__ img, int tid, const uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    int off;
+    if (!KS) off = lds_off_kc(c >> 3, c & 7);
+    else off = lds_off_ks(c >> 4, (c & 15) >> 1, ((c & 15) & 1) << 4);
+    *reinterpret_cast<uint4*>(img + off) = reg[i];
+  }
+}
+
+// fragment of a 16-row tile for k-step ks (32 wide): lane l gets X(row = rt*16 + (l&15), k = ks*32 + 8*(l>>4) + j), j = 0..7
+template <bool KS>
+__device__ __forceinline__ bf16x8 gemm_read_frag(const char* __restrict__ img, int rt, int ks, int lane) {
+  if (!KS) {
+    const int row = rt * 16 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(img + lds_off_kc(row, ks * 4 + (lane >> 4)));
+  } else {
+    // two transposing reads: k rows 8g+q and 8g+4+q (q = (lane&15)>>2 supplies the row address), 4 columns (lane&3)*4..+3
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int ka = ks * 32 + 8 * g + q, kb = ka + 4;
+    typedef __attribute__((address_space(3))) bf16x4* lptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks(ka, rt, p * 8)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks(kb, rt, p * 8)));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool A_KS, bool B_KS, typename CT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A, int64_t lda,
+                                                           const bf16_t* __restrict__ B, int64_t ldb, CT* __restrict__ C, GemmEpi epi,
+                                                           int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware remap (bijective form, cdna_hip_programming T1): blocks that share an XCD (same bid % 8) take a
+  // contiguous run of tiles, n fastest, so an XCD's L2 keeps the A row panel and the whole of W.
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int64_t m0 = (int64_t)(bid / tiles_n) * BM, n0 = (int64_t)(bid % tiles_n) * BN;
+
+  f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  const int nkt = (int)((K + BK - 1) / BK);
+  gemm_load_tile<A_KS>(A, lda, m0, M, 0, K, tid, ra);
+  gemm_load_tile<B_KS>(B, ldb, n0, N, 0, K, tid, rb);
+  gemm_store_tile<A_KS>(smem, tid, ra);
+  gemm_store_tile<B_KS>(smem + TILE_BYTES, tid, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* sb = sa + TILE_BYTES;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      gemm_load_tile<A_KS>(A, lda, m0, M, (int64_t)(kt + 1) * BK, K, tid, ra);
+      gemm_load_tile<B_KS>(B, ldb, n0, N, (int64_t)(kt + 1) * BK, K, tid, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = gemm_read_frag<A_KS>(sa, wm * 4 + t, ks, lane);
+        fb[t] = gemm_read_frag<B_KS>(sb, wn * 4 + t, ks, lane);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+    }
+    if (more) {
+      char* da = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      gemm_store_tile<A_KS>(da, tid, ra);
+      gemm_store_tile<B_KS>(da + TILE_BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+  // epilogue: lane owns row m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0..3} of every 16x16 tile
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int64_t n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+      if (n < N) epilogue_store4<CT>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
+    }
+  }
+}
+
+template <bool A_KS, bool B_KS, typename CT>
+static int launch_bf16(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                       const GemmEpi& epi, hipStream_t st) {
+  const int64_t tm = cdiv(M, BM), tn = cdiv(N, BN);
+  const int64_t nwg = tm * tn;
+  if (nwg > 0x7fffffff) { set_error("gemm: grid too large"); return MAFED_EINVAL; }
+  auto kfn = gemm_bf16_kernel<A_KS, B_KS, CT>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    attr_set = true;
+  }
+  kfn<<<dim3((unsigned)nwg), dim3(256), GEMM_LDS_BYTES, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi,
+                                                               (int)tn, (int)nwg);
+  return MAFED_OK;
+}
+
+}  // namespace mafed
+
+using namespace mafed;
+
+extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                          const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
+                          void* aux, const float* res1, const float* res2, float beta, void* stream) {
+  MAFED_CHECK_ARG(A && B && C, "gemm: null pointer");
+  MAFED_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  MAFED_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm: N=%lld and ldc=%lld must be multiples of 4 (vector epilogue)",
+                  (long long)N, (long long)ldc);
+  MAFED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
+  MAFED_CHECK_ARG(epilogue >= MAFED_EPI_NONE && epilogue <= MAFED_EPI_GELU_BWD, "gemm: unknown epilogue %d", epilogue);
+  MAFED_CHECK_ARG(epilogue != MAFED_EPI_GELU_BWD || aux, "gemm: GELU_BWD epilogue needs aux");
+  MAFED_CHECK_ARG(beta == 0.f || c_dtype == MAFED_F32, "gemm: beta != 0 requires an fp32 C");
+  MAFED_CHECK_ARG((((uintptr_t)C | (uintptr_t)aux | (uintptr_t)res1 | (uintptr_t)res2 | (uintptr_t)bias) & 7) == 0,
+                  "gemm: C/aux/res/bias must be at least 8-byte aligned");
+  if (M == 0) return MAFED_OK;
+  GemmEpi epi{bias, epilogue, aux, res1, res2, beta, ldc};
+  hipStream_t st = as_stream(stream);
+  if (in_dtype == MAFED_F32) {
+    dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64)), block(256);
+    if (c_dtype == MAFED_F32) gemm_f32_kernel<float><<<grid, block, 0, st>>>(transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, epi);
+    else gemm_f32_kernel<bf16_t><<<grid, block, 0, st>>>(transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (bf16_t*)C, epi);
+    MAFED_CHECK_LAUNCH("gemm(f32)");
+    return MAFED_OK;
+  }
+  // bf16 MFMA path: 16-byte operand loads along the contiguous extent
+  MAFED_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0,
+                  "gemm(bf16): A/B must be 16-byte aligned with leading dimensions multiple of 8");
+  MAFED_CHECK_ARG((transA ? M : K) % 8 == 0 && (transB ? K : N) % 8 == 0,
+                  "gemm(bf16): contiguous extents must be multiples of 8 (transA=%d M=%lld K=%lld transB=%d N=%lld)", transA,
+                  (long long)M, (long long)K, transB, (long long)N);
+  const bool a_ks = transA != 0, b_ks = transB == 0;
+  int rc;
+#define GO(AKS, BKS)                                                                                         \
+  rc = (c_dtype == MAFED_F32) ? launch_bf16<AKS, BKS, float>(M, N, K, A, lda, B, ldb, C, epi, st)            \
+                              : launch_bf16<AKS, BKS, bf16_t>(M, N, K, A, lda, B, ldb, C, epi, st)
+  if (!a_ks && !b_ks) GO(false, false);
+  else if (!a_ks && b_ks) GO(false, true);
+  else if (a_ks && b_ks) GO(true, true);
+  else GO(true, false);
+#undef GO
+  if (rc != MAFED_OK) return rc;
+  MAFED_CHECK_LAUNCH("gemm(bf16)");
+  return MAFED_OK;
+}

@@ -1,0 +1,319 @@
+// Dual-affine LayerNorm forward/backward for the fp32 residual stream (tf:243-244,261,272,313).
+// HBM-bound: one wave per token row, 16-byte loads, x read once for both affine outputs.
+#include "common.h"
+
+namespace mafed {
+
+constexpr int LN_ROWS_PER_BLOCK = 4;  // 4 waves of 64
+
+template <int NV, typename OutT>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t rows, int h, float eps,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            OutT* __restrict__ y1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, OutT* __restrict__ y2,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  const float* xr = x + row * h;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    v[i] = (c < h) ? load4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)h;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < h) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)h;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < h) {
+      float4 n = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+      const float4 g1 = load4(w1 + c), o1 = load4(b1 + c);
+      store4(y1 + row * h + c, make_float4(n.x * g1.x + o1.x, n.y * g1.y + o1.y, n.z * g1.z + o1.z, n.w * g1.w + o1.w));
+      if (y2) {
+        const float4 g2 = load4(w2 + c), o2 = load4(b2 + c);
+        store4(y2 + row * h + c, make_float4(n.x * g2.x + o2.x, n.y * g2.y + o2.y, n.z * g2.z + o2.z, n.w * g2.w + o2.w));
+      }
+    }
+  }
+}
+
+// Backward.  Each block walks rows with stride gridDim.x*4; per-lane register partials of the four parameter
+// gradients are combined across the block's 4 waves through LDS and written to workspace [gridDim.x][4][h];
+// ln_param_reduce_kernel then sums the slabs deterministically and accumulates into dw/db.
+template <int NV, typename DyT, bool DUAL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restrict__ dy1, const DyT* __restrict__ dy2,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, int64_t rows, int h,
+                                                            const float* __restrict__ dres, float* __restrict__ dx,
+                                                            DyT* __restrict__ dx_lp, const float* __restrict__ teacher,
+                                                            const int64_t* __restrict__ attention_mask, int S, int P, int T,
+                                                            const float* __restrict__ inj_scale, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [3 waves][NP][h] staging for the cross-wave sum
+  constexpr int NP = DUAL ? 4 : 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 aw1[NV], ab1[NV], aw2[DUAL ? NV : 1], ab2[DUAL ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    aw1[i] = ab1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DUAL) aw2[i] = ab2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 g1[NV], g2[DUAL ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    g1[i] = (c < h) ? load4(w1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DUAL) g2[i] = (c < h) ? load4(w2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float ls = 0.f, vs = 0.f;
+  if (teacher) { ls = inj_scale[0]; vs = inj_scale[1]; }
+  for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], g[NV];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < h) {
+        const float4 xv = load4(x + row * h + c);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        const float4 d1 = load4(dy1 + row * h + c);
+        aw1[i].x += d1.x * xh[i].x; aw1[i].y += d1.y * xh[i].y; aw1[i].z += d1.z * xh[i].z; aw1[i].w += d1.w * xh[i].w;
+        ab1[i].x += d1.x; ab1[i].y += d1.y; ab1[i].z += d1.z; ab1[i].w += d1.w;
+        g[i] = make_float4(d1.x * g1[i].x, d1.y * g1[i].y, d1.z * g1[i].z, d1.w * g1[i].w);
+        if (DUAL) {
+          const float4 d2 = load4(dy2 + row * h + c);
+          aw2[i].x += d2.x * xh[i].x; aw2[i].y += d2.y * xh[i].y; aw2[i].z += d2.z * xh[i].z; aw2[i].w += d2.w * xh[i].w;
+          ab2[i].x += d2.x; ab2[i].y += d2.y; ab2[i].z += d2.z; ab2[i].w += d2.w;
+          g[i].x += d2.x * g2[i].x; g[i].y += d2.y * g2[i].y; g[i].z += d2.z * g2[i].z; g[i].w += d2.w * g2[i].w;
+        }
+        sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        sgx += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      } else {
+        xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float mg = wave_sum(sg) / (float)h, mgx = wave_sum(sgx) / (float)h;
+    float inj = 0.f;
+    if (teacher) {
+      const int cls = modality_class(row, S, P, T, attention_mask);
+      inj = cls == 0 ? ls : (cls == 1 ? vs : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < h) {
+        float4 o = make_float4(rs * (g[i].x - mg - xh[i].x * mgx), rs * (g[i].y - mg - xh[i].y * mgx),
+                               rs * (g[i].z - mg - xh[i].z * mgx), rs * (g[i].w - mg - xh[i].w * mgx));
+        if (dres) {
+          const float4 r = load4(dres + row * h + c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (teacher && inj != 0.f) {
+          const float4 tv = load4(teacher + row * h + c);
+          const float4 xv = load4(x + row * h + c);  // L1/L2 hit: the row was read above
+          o.x += inj * (xv.x - tv.x); o.y += inj * (xv.y - tv.y);
+          o.z += inj * (xv.z - tv.z); o.w += inj * (xv.w - tv.w);
+        }
+        store4(dx + row * h + c, o);
+        if (dx_lp) store4(dx_lp + row * h + c, o);
+      }
+    }
+  }
+  // cross-wave sum of the parameter partials: waves 1..3 stage to LDS, wave 0 adds and writes the block's slab
+  float* stage = lds + (size_t)(wave > 0 ? wave - 1 : 0) * NP * h;
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < h) {
+        store4(stage + 0 * h + c, aw1[i]);
+        store4(stage + 1 * h + c, ab1[i]);
+        if (DUAL) { store4(stage + 2 * h + c, aw2[i]); store4(stage + 3 * h + c, ab2[i]); }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial + (size_t)blockIdx.x * NP * h;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < h) {
+        float4 a = aw1[i], b = ab1[i], c2 = DUAL ? aw2[i] : a, d = DUAL ? ab2[i] : b;
+        for (int w = 0; w < 3; ++w) {
+          const float* st = lds + (size_t)w * NP * h;
+          float4 t0 = load4(st + 0 * h + c), t1 = load4(st + 1 * h + c);
+          a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
+          b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
+          if (DUAL) {
+            float4 t2 = load4(st + 2 * h + c), t3 = load4(st + 3 * h + c);
+            c2.x += t2.x; c2.y += t2.y; c2.z += t2.z; c2.w += t2.w;
+            d.x += t3.x; d.y += t3.y; d.z += t3.z; d.w += t3.w;
+          }
+        }
+        store4(out + 0 * h + c, a);
+        store4(out + 1 * h + c, b);
+        if (DUAL) { store4(out + 2 * h + c, c2); store4(out + 3 * h + c, d); }
+      }
+    }
+  }
+}
+
+// out_k[c] += sum_b partial[b][k][c]   (k = 0..NP-1 -> dw1, db1, dw2, db2); 64 columns x 4 slab groups per block
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblk, int np, int h,
+                                                              float* __restrict__ o0, float* __restrict__ o1,
+                                                              float* __restrict__ o2, float* __restrict__ o3) {
+  __shared__ float sm[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + col;
+  const int tot = np * h;
+  float s = 0.f;
+  if (idx < tot) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = grp;
+    for (; b + 12 < nblk; b += 16) {
+      s0 += partial[(size_t)b * tot + idx];
+      s1 += partial[(size_t)(b + 4) * tot + idx];
+      s2 += partial[(size_t)(b + 8) * tot + idx];
+      s3 += partial[(size_t)(b + 12) * tot + idx];
+    }
+    for (; b < nblk; b += 4) s0 += partial[(size_t)b * tot + idx];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  sm[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && idx < tot) {
+    const float r = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
+    const int k = idx / h, c = idx - k * h;
+    float* o = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+    o[c] += r;
+  }
+}
+
+static int ln_nv(int h) {
+  const int need = (h + 255) / 256;
+  if (need <= 1) return 1;
+  if (need <= 2) return 2;
+  if (need <= 3) return 3;
+  if (need <= 4) return 4;
+  if (need <= 8) return 8;
+  return 0;
+}
+
+static int ln_bwd_blocks(int64_t rows) {
+  int64_t nb = cdiv(rows, LN_ROWS_PER_BLOCK);
+  if (nb > 512) nb = 512;
+  return (int)nb;
+}
+
+}  // namespace mafed
+
+using namespace mafed;
+
+extern "C" int mafed_layernorm_fwd(const float* x, int64_t rows, int h, float eps, const float* w1, const float* b1, void* y1,
+                                   const float* w2, const float* b2, void* y2, mafed_dtype out_dtype, float* mean,
+                                   float* rstd, void* stream) {
+  MAFED_CHECK_ARG(x && w1 && b1 && y1, "layernorm_fwd: null pointer");
+  MAFED_CHECK_ARG(rows >= 0 && h > 0 && h % 4 == 0, "layernorm_fwd: h=%d must be a positive multiple of 4", h);
+  MAFED_CHECK_ARG((y2 == nullptr) == (w2 == nullptr) && (y2 == nullptr) == (b2 == nullptr), "layernorm_fwd: w2/b2/y2 must be all set or all NULL");
+  const int nv = ln_nv(h);
+  MAFED_CHECK_ARG(nv > 0, "layernorm_fwd: h=%d > 2048 unsupported", h);
+  if (rows == 0) return MAFED_OK;
+  dim3 grid((unsigned)cdiv(rows, LN_ROWS_PER_BLOCK)), block(256);
+  hipStream_t st = as_stream(stream);
+#define LAUNCH(NV, T) \
+  layernorm_fwd_kernel<NV, T><<<grid, block, 0, st>>>(x, rows, h, eps, w1, b1, (T*)y1, w2, b2, (T*)y2, mean, rstd)
+#define DISPATCH_T(NV)                      \
+  if (out_dtype == MAFED_F32) LAUNCH(NV, float); \
+  else LAUNCH(NV, bf16_t)
+  switch (nv) {
+    case 1: DISPATCH_T(1); break;
+    case 2: DISPATCH_T(2); break;
+    case 3: DISPATCH_T(3); break;
+    case 4: DISPATCH_T(4); break;
+    default: DISPATCH_T(8); break;
+  }
+#undef DISPATCH_T
+#undef LAUNCH
+  MAFED_CHECK_LAUNCH("layernorm_fwd");
+  return MAFED_OK;
+}
+
+extern "C" size_t mafed_layernorm_bwd_workspace_bytes(int64_t rows, int h) {
+  return (size_t)ln_bwd_blocks(rows) * 4 * (size_t)h * sizeof(float);
+}
+
+extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean,
+                                   const float* rstd, const float* w1, const float* w2, int64_t rows, int h,
+                                   const float* dres, float* dx, void* dx_lp, float* dw1, float* db1, float* dw2, float* db2,
+                                   const float* teacher, const int64_t* attention_mask, int S, int P, int T,
+                                   const float* inj_scale_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  MAFED_CHECK_ARG(dy1 && x && mean && rstd && w1 && dx && dw1 && db1, "layernorm_bwd: null pointer");
+  MAFED_CHECK_ARG(h > 0 && h % 4 == 0, "layernorm_bwd: h=%d must be a positive multiple of 4", h);
+  const bool dual = dy2 != nullptr;
+  MAFED_CHECK_ARG(!dual || (w2 && dw2 && db2), "layernorm_bwd: dual LN needs w2, dw2, db2");
+  MAFED_CHECK_ARG(!teacher || (attention_mask && inj_scale_dev && S > 0 && P >= 0 && T == S - P && rows % S == 0),
+                  "layernorm_bwd: distillation injection needs attention_mask, inj_scale, S=P+T, rows %% S == 0");
+  const int nv = ln_nv(h);
+  MAFED_CHECK_ARG(nv > 0, "layernorm_bwd: h=%d > 2048 unsupported", h);
+  if (rows == 0) return MAFED_OK;
+  const int nblk = ln_bwd_blocks(rows);
+  const int np = dual ? 4 : 2;
+  if (workspace_bytes < (size_t)nblk * np * h * sizeof(float) || !workspace) {
+    set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, (size_t)nblk * np * h * sizeof(float));
+    return MAFED_EWORKSPACE;
+  }
+  const size_t lds_bytes = (size_t)3 * np * h * sizeof(float);
+  MAFED_CHECK_ARG(lds_bytes <= 160 * 1024, "layernorm_bwd: LDS staging %zu too large", lds_bytes);
+  hipStream_t st = as_stream(stream);
+  float* partial = (float*)workspace;
+  dim3 grid(nblk), block(256);
+#define LAUNCH(NV, T, DUAL)                                                                                              \
+  do {                                                                                                                   \
+    auto kfn = layernorm_bwd_kernel<NV, T, DUAL>;                                                                        \
+    if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+    kfn<<<grid, block, lds_bytes, st>>>((const T*)dy1, (const T*)dy2, x, mean, rstd, w1, w2, rows, h, dres, dx, (T*)dx_lp, \
+                                        teacher, attention_mask, S, P, T_, inj_scale_dev, partial);                      \
+  } while (0)
+  const int T_ = T;
+#define DISPATCH_D(NV, TT) \
+  if (dual) LAUNCH(NV, TT, true); \
+  else LAUNCH(NV, TT, false)
+#define DISPATCH_T(NV)                          \
+  if (dy_dtype == MAFED_F32) { DISPATCH_D(NV, float); } \
+  else { DISPATCH_D(NV, bf16_t); }
+  switch (nv) {
+    case 1: DISPATCH_T(1); break;
+    case 2: DISPATCH_T(2); break;
+    case 3: DISPATCH_T(3); break;
+    case 4: DISPATCH_T(4); break;
+    default: DISPATCH_T(8); break;
+  }
+#undef DISPATCH_T
+#undef DISPATCH_D
+#undef LAUNCH
+  MAFED_CHECK_LAUNCH("layernorm_bwd");
+  const int tot = np * h;
+  ln_param_reduce_kernel<<<dim3((tot + 63) / 64), dim3(256), 0, st>>>(partial, nblk, np, h, dw1, db1, dw2, db2);
+  MAFED_CHECK_LAUNCH("layernorm_bwd(param reduce)");
+  return MAFED_OK;
+}

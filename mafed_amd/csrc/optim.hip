@@ -1,0 +1,130 @@
+// Flat-buffer optimiser kernels: global gradient L2 norm + clip scale (Lightning gradient_clip_val,
+// mafed/train.py:288) and HF-style AdamW (mafed/optim/adamw.py:86-111).  HBM-bound streaming, 16-byte accesses.
+#include "common.h"
+
+namespace mafed {
+
+constexpr int GN_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+  __shared__ float sm[4];
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 a = load4(g + i * 4), b = load4(g + (i + stride) * 4);
+    s0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    s1 += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+  }
+  for (; i < n4; i += stride) {
+    const float4 a = load4(g + i * 4);
+    s0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+    const float a = g[n4 * 4 + threadIdx.x];
+    s0 += a * a;
+  }
+  const float s = block_sum<256>(s0 + s1, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm,
+                                                              float* __restrict__ out2) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += partial[b];
+  s = block_sum<256>(s, sm);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(s);
+    out2[0] = norm;
+    out2[1] = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+  }
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float beta1,
+                                                    float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ clip_dev, float grad_mul, bf16_t* __restrict__ p_bf16) {
+  const float lr = lr_dev[0];
+  const float gs = grad_mul * (clip_dev ? clip_dev[1] : 1.0f);
+  const float step_size = lr * bc2_sqrt / bc1;
+  const float decay = lr * wd;
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = load4(p + i * 4), gg = load4(g + i * 4), mm = load4(m + i * 4), vv = load4(v + i * 4);
+    float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = ga[k] * gs;
+      ma[k] = ma[k] * beta1 + (1.0f - beta1) * gk;
+      va[k] = va[k] * beta2 + (1.0f - beta2) * gk * gk;
+      const float denom = sqrtf(va[k]) + eps;
+      float x = pa[k] - step_size * (ma[k] / denom);
+      if (wd > 0.f) x = x - decay * x;
+      pa[k] = x;
+    }
+    store4(p + i * 4, pp); store4(m + i * 4, mm); store4(v + i * 4, vv);
+    if (SHADOW) store4(p_bf16 + i * 4, pp);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    const float gk = g[i] * gs;
+    const float mk = m[i] * beta1 + (1.0f - beta1) * gk;
+    const float vk = v[i] * beta2 + (1.0f - beta2) * gk * gk;
+    float x = p[i] - step_size * (mk / (sqrtf(vk) + eps));
+    if (wd > 0.f) x = x - decay * x;
+    p[i] = x; m[i] = mk; v[i] = vk;
+    if (SHADOW) p_bf16[i] = f32_to_bf16(x);
+  }
+}
+
+}  // namespace mafed
+
+using namespace mafed;
+
+extern "C" size_t mafed_gradnorm_workspace_bytes(int64_t n) { (void)n; return (size_t)GN_BLOCKS * sizeof(float); }
+
+extern "C" int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, float* out2, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  MAFED_CHECK_ARG(g && out2 && n >= 0, "gradnorm_clip: bad arguments");
+  MAFED_CHECK_ARG(((uintptr_t)g & 15) == 0, "gradnorm_clip: g must be 16-byte aligned");
+  if (!workspace || workspace_bytes < GN_BLOCKS * sizeof(float)) {
+    set_error("gradnorm_clip: workspace %zu < %zu", workspace_bytes, (size_t)GN_BLOCKS * sizeof(float));
+    return MAFED_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  int64_t nb = cdiv(n / 4 + 1, 256 * 4);
+  if (nb > GN_BLOCKS) nb = GN_BLOCKS;
+  if (nb < 1) nb = 1;
+  gradnorm_partial_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(g, n, (float*)workspace);
+  MAFED_CHECK_LAUNCH("gradnorm(partial)");
+  gradnorm_finish_kernel<<<dim3(1), dim3(256), 0, st>>>((const float*)workspace, (int)nb, max_norm, out2);
+  MAFED_CHECK_LAUNCH("gradnorm(finish)");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                                float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
+                                void* stream) {
+  MAFED_CHECK_ARG(p && g && m && v && lr_dev && n >= 0 && step >= 1, "adamw_step: bad arguments");
+  MAFED_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step: buffers must be 16-byte aligned");
+  MAFED_CHECK_ARG(!p_bf16 || ((uintptr_t)p_bf16 & 7) == 0, "adamw_step: p_bf16 must be 8-byte aligned");
+  if (n == 0) return MAFED_OK;
+  // bias corrections in double on the host, exactly as math.sqrt(1 - b2**t) / (1 - b1**t) (adamw.py:94-97)
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipStream_t st = as_stream(stream);
+  int64_t nb = cdiv(n / 4 + 1, 256);
+  if (nb > 4096) nb = 4096;
+  if (p_bf16)
+    adamw_kernel<true><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, (float)bc1,
+                                                                 (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16);
+  else
+    adamw_kernel<false><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, (float)bc1,
+                                                                  (float)sqrt(bc2), clip_dev, grad_mul, nullptr);
+  MAFED_CHECK_LAUNCH("adamw_step");
+  return MAFED_OK;
+}

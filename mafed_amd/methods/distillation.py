@@ -1,0 +1,219 @@
+"""MAFED -- feature distillation with separate vision / language weights (reference: mafed/methods/distillation.py).
+
+Same constructor kwargs and method names as the reference plugin.  The per-layer, per-modality arithmetic runs in
+the fused dual-mask kernels (``mafed_distill_fwd/bwd``): one pass over a layer's student/teacher hidden states
+yields both modality sums; all layers go through ONE autograd node, the scalar algebra (counts, modality weights,
+layer coefficients) is vectorised over layers on the device, and nothing synchronises with the host (the
+reference's per-layer ``wandb.log(.item())``, distillation.py:165, becomes ``self.last_layer_losses``).
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from mafed_amd import ops
+from mafed_amd.methods.base import CLStrategy
+from mafed_amd.methods.distillation_loss_weights import DistillationWeights
+from mafed_amd.methods.memory import HBMReplayBuffer
+
+
+class _DistillSumsFn(torch.autograd.Function):
+    """sums[l] = {sum_lang d, sum_vision d, n_lang, n_vision} for every distilled layer l (d = per-token MSE or 1-cos)."""
+
+    @staticmethod
+    def forward(ctx, attention_mask, P, cosine, teacher: Sequence[torch.Tensor], *student):
+        nl = len(student)
+        out = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
+        for l in range(nl):
+            ops.distill_fwd(student[l], teacher[l], attention_mask, P, cosine, out=out[l])
+        ctx.am, ctx.P, ctx.cosine, ctx.teacher = attention_mask, P, cosine, list(teacher)
+        ctx.save_for_backward(*student)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        student = ctx.saved_tensors
+        g = g.contiguous()
+        grads = []
+        for l, s in enumerate(student):
+            if ctx.needs_input_grad[4 + l]:
+                grads.append(ops.distill_bwd(s, ctx.teacher[l], ctx.am, ctx.P, g[l], ctx.cosine))
+            else:
+                grads.append(None)
+        return (None, None, None, None, *grads)
+
+
+class _DistillClsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, t):
+        ctx.save_for_backward(s, t)
+        return ops.distill_cls_fwd(s, t).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t = ctx.saved_tensors
+        coef = (g.reshape(1) / s.shape[0]).contiguous()
+        return ops.distill_cls_bwd(s, t, coef), None
+
+
+class FeatureDistillation(CLStrategy):
+    """Feature Distillation with Separate Vision & Language Weights (MAFED)."""
+
+    def __init__(self, memory_size, opts, model_type, distillation_modality_weighing_strategy="equal",
+                 distillation_layer_weighing_strategy="single", distillation_coeff=1.0, replay_coeff=1.0,
+                 distillation_layer=-1, cls_distillation=False, distillation_loss="mse", gamma: float = 0.8,
+                 num_hidden_layers: int = 11, **kwargs):
+        super().__init__(opts=opts, **{k: v for k, v in kwargs.items() if k in ("reg_lambda", "mask", "scaler")})
+        self.memory_size = memory_size
+        num_mem_tasks = len(opts.tasks) - 1
+        self.memory_per_task = int(memory_size / num_mem_tasks)
+        self.batch_size = opts.batch_size
+        self.num_workers = getattr(opts, "n_workers", 0)
+        self.seed = 1
+        self.datasets: List = []
+        self.rng = np.random.default_rng(opts.seed)  # memory sub-sampling stream, as upstream (distillation.py:45)
+        self.pin_mem = getattr(opts, "pin_mem", False)
+        self.step = 0
+        self.model_type = model_type
+        self.past_model = None
+        self.replay_coeff = replay_coeff
+        self.distillation_coeff = distillation_coeff
+        self.weighing_strategy = distillation_modality_weighing_strategy
+        self._cls_distillation = cls_distillation
+        self._cosine = distillation_loss == "cosine"
+        # a layer outside [0, num_hidden_layers) means "no single layer" (distillation.py:61-64)
+        layer = distillation_layer if (distillation_layer is not None and 0 <= distillation_layer < num_hidden_layers) else None
+        self.loss_weights = DistillationWeights(
+            distillation_modality_weighing_strategy=distillation_modality_weighing_strategy,
+            distillation_layer_weighing_strategy=distillation_layer_weighing_strategy, gamma=gamma,
+            num_hidden_layers=num_hidden_layers, distillation_layer=layer)
+        self.opts = opts
+        self.num_vision_tokens = 256  # hard-coded upstream (distillation.py:73); instance attribute, settable
+        self.mem_dataloader = None
+        self.last_layer_losses: Optional[torch.Tensor] = None  # [n_layers] device tensor of the last distill() call
+        self.last_modality_losses: Optional[torch.Tensor] = None  # [n_layers, 2] (lang, vision)
+
+    # ---- between tasks -----------------------------------------------------------------------------------------------
+    def update(self, dataset, model, dataloader, mask=None, **kwargs):
+        self._update_model(model)
+        self._update_memory(dataset)
+        self.loss_weights.update_weights(model, dataloader, self.task_id)
+        self.task_id += 1
+
+    def _update_model(self, model):
+        """Teacher := frozen copy of the finished task's model (distillation.py:211-213)."""
+        self.past_model = deepcopy(model)
+        self.past_model.eval()
+        for p in self.past_model.parameters():
+            p.requires_grad_(False)
+
+    def _update_memory(self, dataset):
+        """Keep ``memory_per_task`` random samples of the finished task (distillation.py:182-209).
+
+        ``dataset`` may be (a) an ``HBMReplayBuffer``-compatible dict of collated tensors, (b) any map-style dataset
+        whose items are dicts of tensors of equal text length (collated with torch.stack)."""
+        n = len(dataset["input_ids"]) if isinstance(dataset, dict) else len(dataset)
+        k = min(self.memory_per_task, n)
+        idx = self.rng.choice(np.arange(n), k, replace=False)
+        assert len(set(idx.tolist())) == k
+        self.seed = 1
+        if isinstance(dataset, dict):
+            sel = torch.as_tensor(np.sort(idx))
+            samples = {key: dataset[key][sel] for key in HBMReplayBuffer.KEYS}
+        else:
+            items = [dataset[int(i)] for i in idx]
+            samples = {key: torch.stack([torch.as_tensor(it[key]) for it in items]) for key in HBMReplayBuffer.KEYS}
+        self.datasets.append(samples)
+        if not isinstance(self.mem_dataloader, HBMReplayBuffer):
+            import torch.distributed as dist
+            rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+            dev = self.past_model.flat_params.device if hasattr(self.past_model, "flat_params") else samples["input_ids"].device
+            self.mem_dataloader = HBMReplayBuffer(self.batch_size, dev, seed=self.opts.seed, rank=rank, world_size=world)
+        self.mem_dataloader.add(samples)
+
+    def update_mask(self, mask=None):
+        return None
+
+    def update_after_new_task(self, model, dataset):
+        if self.weighing_strategy != "loss_based":  # never true upstream either (distillation.py:168-173)
+            return
+        raise NotImplementedError("loss_based weighing does not exist in the reference code path")
+
+    def update_after_step(self, model, batch_idx=0, on_train_start=False):
+        if self.task_id == 0 or self.weighing_strategy != "dynamic":
+            return
+        raise NotImplementedError("dynamic weighing does not exist in the reference code path")
+
+    # ---- inside a step ---------------------------------------------------------------------------------------------------
+    def compute_loss(self, model, loss, batch=None, **kwargs):
+        return loss
+
+    def replay(self, model):
+        """Memory batch -> replay CE (iff replay_coeff > 0 and task_id > 0) + distillation (distillation.py:84-103)."""
+        batch = next(iter(self.mem_dataloader))
+        n_ex = batch["input_ids"].size(0)
+        do_replay = self.replay_coeff > 0 and self.task_id > 0
+        output = model(**batch, compute_loss=do_replay, output_hidden_states=True, return_dict=True)
+        loss = self.replay_coeff * output.loss if do_replay else None
+        if self.distillation_coeff == 0:
+            return loss, n_ex
+        dloss = self.distill(output=output, batch=batch)
+        loss = dloss if loss is None else loss + dloss
+        return loss, n_ex
+
+    def _get_past_hidden_states(self, batch, n_hidden: Optional[int] = None):
+        """Frozen-teacher hidden states; pops ``labels`` from the caller's dict like upstream (distillation.py:218-224)."""
+        batch.pop("labels", None)
+        pm = self.past_model
+        with torch.no_grad():
+            if hasattr(pm, "hidden_states_upto"):
+                kw = {"patch_embeddings": batch["patch_embeddings"]} if "patch_embeddings" in batch else {"pixel_values": batch["pixel_values"]}
+                return [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=n_hidden, **kw)]
+            hs = pm(**batch, output_hidden_states=True, return_dict=True).hidden_states
+            return [x.detach() for x in hs]
+
+    def distill(self, output, batch):
+        layers = self.loss_weights.get_distillation_layers()
+        past = self._get_past_hidden_states(batch, n_hidden=max(layers) + 1)
+        dev = output.hidden_states[0].device
+        coeffs = self.loss_weights.layer_coeff_vector(dev) * float(self.distillation_coeff)
+        P = self.num_vision_tokens
+        am = batch["attention_mask"].to(dev, torch.int64).contiguous()
+        if self._cls_distillation:
+            if not self._cosine:
+                # upstream passes three tensors to MSELoss here and raises
+                raise TypeError("cls_distillation requires distillation_loss='cosine'")
+            per_layer = torch.stack([_DistillClsFn.apply(output.hidden_states[l].contiguous(), past[l].contiguous()) for l in layers])
+            self.last_modality_losses = None
+        else:
+            B, T = am.shape
+            lm = torch.zeros((B, T + P), dtype=am.dtype, device=dev)
+            lm[:, P:] = am
+            im = torch.zeros((B, T + P), dtype=am.dtype, device=dev)
+            im[:, :P] = 1
+            batch["lang_masks"], batch["image_masks"] = lm, im  # side effect kept (distillation.py:139,144)
+            students = [output.hidden_states[l] for l in layers]
+            teachers = [past[l] for l in layers]
+            sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
+            lang = sums[:, 0] / sums[:, 2]
+            vis = sums[:, 1] / sums[:, 3]
+            lw, vw = self.loss_weights.modality_weight_vectors(sums[0, 2].detach(), sums[0, 3].detach(), layers, dev)
+            per_layer = lw * lang + vw * vis
+            self.last_modality_losses = torch.stack([lang, vis], dim=1).detach()
+        self.last_layer_losses = per_layer.detach()
+        self.step += 1
+        return (coeffs * per_layer).sum()
+
+    # kept for API parity with the reference's per-layer entry point (distillation.py:124-166)
+    def feature_distillation(self, batch, hidden_states, past_hidden_states, layer: int):
+        dev = hidden_states.device
+        if self._cls_distillation:
+            return _DistillClsFn.apply(hidden_states.contiguous(), past_hidden_states.contiguous())
+        am = batch["attention_mask"].to(dev, torch.int64).contiguous()
+        P = self.num_vision_tokens
+        sums = _DistillSumsFn.apply(am, P, self._cosine, [past_hidden_states], hidden_states)
+        lw, vw = self.loss_weights.modality_weight_vectors(sums[0, 2].detach(), sums[0, 3].detach(), [layer], dev)
+        return (lw * sums[:, 0] / sums[:, 2] + vw * sums[:, 1] / sums[:, 3])[0]

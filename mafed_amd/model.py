@@ -1,0 +1,573 @@
+"""VLPythia (image-patch prefix + GPT-NeoX decoder) on hand-written gfx950 kernels.
+
+Mirrors the reference model surface for the training hot path:
+  * ``model_architecture["vlpythia"]`` registry (mafed/model/__init__.py:3-5)
+  * state-dict names/shapes of ``VLCLIPGPTNeoXForCausalLM`` (mafed/model/vl_pythia.py:209-237) so reference
+    checkpoints load: ``gpt_neox.embed_in.weight``, ``gpt_neox.layers.{i}.*``, ``gpt_neox.final_layer_norm.*``,
+    ``embed_out.weight``, ``vision_embed_tokens.{0,2}.*``
+  * ``model(input_ids=, pixel_values=, attention_mask=, labels=, output_hidden_states=, return_dict=True, **kw)``
+    -> object with ``.loss``, ``.logits``, ``.hidden_states`` (mafed/model/vl_pythia.py:247-326)
+
+Differences kept deliberately small and documented in DESIGN.md: the frozen vision encoder is the path's input
+boundary (``pixel_values`` may be pre-computed ``[B,1+P,Dv]``/``[B,P,Dv]`` features, or a user-supplied frozen
+``vision_encoder`` module is called on images); ``.logits`` covers the T text positions only (the reference computes
+all S positions and uses the last T, vl_pythia.py:89,310).
+
+The forward/backward of the whole model is ONE autograd node with a hand-scheduled backward (no per-op autograd
+graph): activations live in plain buffers, parameter gradients are accumulated by the kernels straight into a flat
+fp32 gradient buffer (the RCCL bucket source), hidden-state gradients coming from the distillation loss are injected
+at the layer boundaries.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from mafed_amd import ops
+from mafed_amd._lib import EPI_GELU, EPI_GELU_BWD, EPI_NONE
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@dataclass
+class VLPythiaConfig:
+    """Fields of config/vlpythia-base.json that the path reads."""
+
+    vocab_size: int = 50304
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    intermediate_size: int = 4096
+    rotary_pct: float = 0.25
+    rotary_emb_base: float = 10000.0
+    layer_norm_eps: float = 1e-5
+    initializer_range: float = 0.02
+    vision_hidden_size: int = 1024     # EVA02-L / CLIP-L feature width
+    num_vision_tokens: int = 256       # patches kept by feature_select("patch")
+    use_parallel_residual: bool = True
+    select_feature: str = "patch"
+
+    PRESETS = {"160m": (768, 12, 12), "410m": (1024, 24, 16), "1b": (2048, 16, 8), "1.4b": (2048, 24, 16)}
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def rotary_ndims(self) -> int:
+        return int(self.head_dim * self.rotary_pct)
+
+    @classmethod
+    def preset(cls, name: str, **kw) -> "VLPythiaConfig":
+        h, L, H = cls.PRESETS[name]
+        return cls(hidden_size=h, num_hidden_layers=L, num_attention_heads=H, intermediate_size=4 * h, **kw)
+
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]) -> "VLPythiaConfig":
+        keys = {f for f in cls.__dataclass_fields__}
+        return cls(**{k: v for k, v in d.items() if k in keys})
+
+
+@dataclass
+class CausalLMOutput:
+    """Stand-in for transformers' CausalLMOutputWithPast (mafed/model/vl_pythia.py:320-326)."""
+
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Any = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Any = None
+
+    def __getitem__(self, i):
+        return tuple(v for v in (self.loss, self.logits, self.hidden_states) if v is not None)[i]
+
+
+# parameter holders: modules without a forward; the tree only exists so that state-dict names match the reference
+class _Affine(nn.Module):
+    def __init__(self, w: nn.Parameter, b: Optional[nn.Parameter]):
+        super().__init__()
+        self.weight = w
+        if b is not None:
+            self.bias = b
+
+
+class _FrozenVision(nn.Module):
+    """Placeholder for the frozen encoder (vqa_cont_learner.py:202-203 freezes ``model.vision_encoder.parameters()``)."""
+
+    def __init__(self, encoder: Optional[nn.Module] = None):
+        super().__init__()
+        if encoder is not None:
+            self.encoder = encoder
+
+    def forward(self, x):
+        enc = getattr(self, "encoder", None)
+        if enc is None:
+            return x
+        with torch.no_grad():
+            return enc.forward_features(x) if hasattr(enc, "forward_features") else enc(x)
+
+
+NO_DECAY_KEYS = ("bias", "LayerNorm.bias", "LayerNorm.weight", "vqa_output_distill_loss_params")
+
+
+def is_no_decay(name: str) -> bool:
+    """Name test of BaseModule.configure_optimizers (vqa_cont_learner.py:73-78): GPT-NeoX LayerNorm parameters are
+    called ``*layernorm.*`` (lower case), so only names containing ``bias`` escape weight decay."""
+    return any(k in name for k in NO_DECAY_KEYS)
+
+
+def _param_specs(cfg: VLPythiaConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    h, ff, V, dv = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.vision_hidden_size
+    out: List[Tuple[str, Tuple[int, ...]]] = [("gpt_neox.embed_in.weight", (V, h))]
+    for i in range(cfg.num_hidden_layers):
+        p = f"gpt_neox.layers.{i}."
+        out += [(p + "input_layernorm.weight", (h,)), (p + "input_layernorm.bias", (h,)),
+                (p + "post_attention_layernorm.weight", (h,)), (p + "post_attention_layernorm.bias", (h,)),
+                (p + "attention.query_key_value.weight", (3 * h, h)), (p + "attention.query_key_value.bias", (3 * h,)),
+                (p + "attention.dense.weight", (h, h)), (p + "attention.dense.bias", (h,)),
+                (p + "mlp.dense_h_to_4h.weight", (ff, h)), (p + "mlp.dense_h_to_4h.bias", (ff,)),
+                (p + "mlp.dense_4h_to_h.weight", (h, ff)), (p + "mlp.dense_4h_to_h.bias", (h,))]
+    out += [("gpt_neox.final_layer_norm.weight", (h,)), ("gpt_neox.final_layer_norm.bias", (h,)),
+            ("embed_out.weight", (V, h)),
+            ("vision_embed_tokens.0.weight", (h, dv)), ("vision_embed_tokens.0.bias", (h,)),
+            ("vision_embed_tokens.2.weight", (h, h)), ("vision_embed_tokens.2.bias", (h,))]
+    return out
+
+
+class VLPythiaForCausalLM(nn.Module):
+    """MI355X-native counterpart of ``VLCLIPGPTNeoXForCausalLM`` for the training hot path."""
+
+    def __init__(self, config: VLPythiaConfig, compute_dtype: torch.dtype = torch.bfloat16, device: Any = None,
+                 vision_encoder: Optional[nn.Module] = None, seed: Optional[int] = None):
+        super().__init__()
+        assert compute_dtype in (torch.bfloat16, torch.float32)
+        assert config.use_parallel_residual, "GPT-NeoX sequential residual is not on the MAFED path (config/vlpythia-base.json:30)"
+        self.config = config
+        self.compute_dtype = compute_dtype
+        dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        specs = _param_specs(config)
+        # flat layout: [decayed ...][non-decayed ...], every tensor starts on a 64-element boundary
+        order = [s for s in specs if not is_no_decay(s[0])] + [s for s in specs if is_no_decay(s[0])]
+        offs, off = {}, 0
+        n_decay_end = 0
+        for name, shape in order:
+            n = int(math.prod(shape))
+            offs[name] = (off, n, shape)
+            off += (n + 63) // 64 * 64
+            if not is_no_decay(name):
+                n_decay_end = off
+        self._offsets = offs
+        self._n_flat = off
+        self._n_decay = n_decay_end
+        self.flat_params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        self._shadow_dirty = True
+        self._build_tree(specs)
+        self.vision_encoder = _FrozenVision(vision_encoder)
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._rot_cache: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        # callable(i): fired when layer i's parameter gradients are final for this backward; i = L for the LM head /
+        # final LayerNorm, -1 when everything (embeddings, projector) is done.  Used by the DDP bucket reducer.
+        self.grad_ready_hook = None
+        self.reset_parameters(seed)
+        self.register_load_state_dict_post_hook(lambda m, ik: setattr(m, "_shadow_dirty", True))
+
+    # ---- construction ---------------------------------------------------------------------------------------
+    def _build_tree(self, specs):
+        params: Dict[str, nn.Parameter] = {}
+        for name, shape in specs:
+            o, n, _ = self._offsets[name]
+            p = nn.Parameter(self.flat_params[o:o + n].view(shape))
+            p.grad = self.flat_grads[o:o + n].view(shape)
+            params[name] = p
+        self._params_by_name = params
+        cfg = self.config
+        neox = nn.Module()
+        neox.embed_in = _Affine(params["gpt_neox.embed_in.weight"], None)
+        layers = nn.ModuleList()
+        for i in range(cfg.num_hidden_layers):
+            pre = f"gpt_neox.layers.{i}."
+            lyr = nn.Module()
+            lyr.input_layernorm = _Affine(params[pre + "input_layernorm.weight"], params[pre + "input_layernorm.bias"])
+            lyr.post_attention_layernorm = _Affine(params[pre + "post_attention_layernorm.weight"], params[pre + "post_attention_layernorm.bias"])
+            att = nn.Module()
+            att.query_key_value = _Affine(params[pre + "attention.query_key_value.weight"], params[pre + "attention.query_key_value.bias"])
+            att.dense = _Affine(params[pre + "attention.dense.weight"], params[pre + "attention.dense.bias"])
+            lyr.attention = att
+            mlp = nn.Module()
+            mlp.dense_h_to_4h = _Affine(params[pre + "mlp.dense_h_to_4h.weight"], params[pre + "mlp.dense_h_to_4h.bias"])
+            mlp.dense_4h_to_h = _Affine(params[pre + "mlp.dense_4h_to_h.weight"], params[pre + "mlp.dense_4h_to_h.bias"])
+            lyr.mlp = mlp
+            layers.append(lyr)
+        neox.layers = layers
+        neox.final_layer_norm = _Affine(params["gpt_neox.final_layer_norm.weight"], params["gpt_neox.final_layer_norm.bias"])
+        self.gpt_neox = neox
+        self.embed_out = _Affine(params["embed_out.weight"], None)
+        vt = nn.Module()
+        setattr(vt, "0", _Affine(params["vision_embed_tokens.0.weight"], params["vision_embed_tokens.0.bias"]))
+        setattr(vt, "2", _Affine(params["vision_embed_tokens.2.weight"], params["vision_embed_tokens.2.bias"]))
+        self.vision_embed_tokens = vt
+
+    def reset_parameters(self, seed: Optional[int] = None):
+        """HF init distribution: Linear/Embedding N(0, initializer_range), LayerNorm (1, 0), biases 0."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(0 if seed is None else int(seed))
+        with torch.no_grad():
+            for name, p in self._params_by_name.items():
+                if "layernorm" in name or "layer_norm" in name:
+                    p.fill_(1.0 if name.endswith("weight") else 0.0)
+                elif name.endswith("bias"):
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * self.config.initializer_range)
+        self._shadow_dirty = True
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name: str, vision_encoder_name: str = "", select_layer: int = -2,
+                        select_feature: str = "patch", use_flash_attention_2: bool = False, state_dict=None, **kw):
+        """Signature of the reference loader (mafed/model/vl_pythia.py:385-394) for a LOCAL directory holding
+        ``config.json`` and ``model.safetensors`` / ``pytorch_model.bin``; hub names need network and are refused."""
+        import json
+        import os
+        if not os.path.isdir(pretrained_model_name):
+            raise ValueError(f"{pretrained_model_name!r} is not a local directory (no network access on this path)")
+        with open(os.path.join(pretrained_model_name, "config.json")) as fp:
+            cfg = VLPythiaConfig.from_dict(json.load(fp))
+        model = cls(cfg, **kw)
+        st = os.path.join(pretrained_model_name, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(pretrained_model_name, "pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("vision_encoder.")}, strict=False)
+        if state_dict is not None:
+            model.load_state_dict(state_dict, strict=False)
+        return model
+
+    def __deepcopy__(self, memo):
+        """Teacher snapshot (mafed/methods/distillation.py:211-213): one flat device copy instead of a per-tensor walk."""
+        enc = getattr(self.vision_encoder, "encoder", None)
+        new = VLPythiaForCausalLM(self.config, self.compute_dtype, self.flat_params.device, vision_encoder=enc)
+        with torch.no_grad():
+            new.flat_params.copy_(self.flat_params)
+        new._shadow_dirty = True
+        new.train(self.training)
+        return new
+
+    def _apply(self, fn, recurse=True):
+        """``.to(device)`` / ``.cuda()``: move the flat buffers and re-point every parameter view at them."""
+        probe = fn(self.flat_params)
+        if probe.device != self.flat_params.device or probe.dtype != self.flat_params.dtype:
+            if probe.dtype != torch.float32:
+                raise TypeError("master weights stay fp32; choose compute_dtype at construction")
+            self.flat_params = probe
+            self.flat_grads = fn(self.flat_grads)
+            if self.flat_shadow is not None:
+                self.flat_shadow = self.flat_shadow.to(probe.device)
+            self._anchor = torch.zeros(1, device=probe.device, requires_grad=True)
+            for name, p in self._params_by_name.items():
+                o, n, shape = self._offsets[name]
+                p.data = self.flat_params[o:o + n].view(shape)
+                p.grad = self.flat_grads[o:o + n].view(shape)
+            self._rot_cache.clear()
+            self._shadow_dirty = True
+            enc = getattr(self.vision_encoder, "encoder", None)
+            if enc is not None:
+                enc._apply(fn)
+            return self
+        return self
+
+    # ---- parameter views ---------------------------------------------------------------------------------------
+    def sync_shadow(self):
+        """Refresh the bf16 copy of the weights read by the MFMA GEMMs (the optimiser kernel keeps it current)."""
+        if self.flat_shadow is not None and self.flat_params.is_cuda:
+            ops.cast(self.flat_params, torch.bfloat16, out=self.flat_shadow)
+        self._shadow_dirty = False
+
+    def _w(self, name: str) -> torch.Tensor:
+        """Weight in compute dtype."""
+        o, n, shape = self._offsets[name]
+        src = self.flat_shadow if self.compute_dtype == torch.bfloat16 else self.flat_params
+        return src[o:o + n].view(shape)
+
+    def _p(self, name: str) -> torch.Tensor:
+        o, n, shape = self._offsets[name]
+        return self.flat_params[o:o + n].view(shape)
+
+    def _g(self, name: str) -> torch.Tensor:
+        o, n, shape = self._offsets[name]
+        return self.flat_grads[o:o + n].view(shape)
+
+    def zero_grad(self, set_to_none: bool = False):  # gradients are views of the flat buffer: always zero in place
+        self.flat_grads.zero_()
+
+    def decay_split(self) -> int:
+        """flat[:n] is weight-decayed, flat[n:] is not."""
+        return self._n_decay
+
+    def rotary_tables(self, S: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """cos/sin [S, rot/2] fp32 (GPTNeoXRotaryEmbedding, tf:52-108; positions = arange(S), pads not skipped)."""
+        key = (S, str(self.flat_params.device))
+        if key not in self._rot_cache:
+            rd = self.config.rotary_ndims
+            inv = 1.0 / (self.config.rotary_emb_base ** (torch.arange(0, rd, 2, dtype=torch.float32) / rd))
+            fr = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+            self._rot_cache[key] = (fr.cos().contiguous().to(self.flat_params.device), fr.sin().contiguous().to(self.flat_params.device))
+        return self._rot_cache[key]
+
+    # ---- public forward ------------------------------------------------------------------------------------------
+    def get_patch_embeddings(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """get_patch_embeddings + feature_select (mafed/model/vl_pythia.py:453-475); features pass through."""
+        P, dv = self.config.num_vision_tokens, self.config.vision_hidden_size
+        x = pixel_values
+        if x.dim() == 4:
+            x = self.vision_encoder(x)
+        if x.dim() != 3 or x.shape[-1] != dv:
+            raise ValueError(f"expected vision features [B,{P}(+1),{dv}], got {tuple(x.shape)}")
+        if x.shape[1] == P + 1 and self.config.select_feature == "patch":
+            x = x[:, 1:]
+        if x.shape[1] != P:
+            raise ValueError(f"expected {P} patch tokens, got {x.shape[1]}")
+        return x
+
+    def forward(self, input_ids: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None,
+                attention_mask: Optional[torch.Tensor] = None, position_ids=None, inputs_embeds=None, head_mask=None,
+                past_key_values=None, labels: Optional[torch.Tensor] = None, use_cache=None, output_attentions=None,
+                output_hidden_states: Optional[bool] = None, return_dict: Optional[bool] = None,
+                allow_input_gradients: bool = False, patch_embeddings: Optional[torch.Tensor] = None, **kwargs):
+        if input_ids is None or (pixel_values is None and patch_embeddings is None):
+            raise ValueError("the training path needs input_ids and pixel_values / patch_embeddings")
+        if position_ids is not None or inputs_embeds is not None or past_key_values is not None or use_cache or output_attentions:
+            raise NotImplementedError("position_ids / inputs_embeds / KV cache / attentions are outside the MAFED training path")
+        feats = patch_embeddings if patch_embeddings is not None else self.get_patch_embeddings(pixel_values)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        want_h = bool(output_hidden_states)
+        dev = self.flat_params.device
+        input_ids = input_ids.to(dev, torch.int64).contiguous()
+        attention_mask = attention_mask.to(dev, torch.int64).contiguous()
+        labels = labels.to(dev, torch.int64).contiguous() if labels is not None else None
+        feats = feats.to(dev).contiguous()
+        if torch.is_grad_enabled():
+            outs = _ModelFn.apply(self._anchor, self, feats, input_ids, attention_mask, labels, want_h)
+            loss = outs[0] if labels is not None else None
+            logits, hs = outs[1], tuple(outs[2:]) if want_h else None
+        else:
+            st = self._engine_forward(feats, input_ids, attention_mask, labels, want_h, train=False)
+            loss = st["loss"].reshape(()) if st["loss"] is not None else None
+            logits, hs = st["logits"], tuple(st["hidden"]) if want_h else None
+        out = CausalLMOutput(loss=loss, logits=logits, hidden_states=hs)
+        if return_dict is False:
+            return tuple(v for v in (out.loss, out.logits, out.hidden_states) if v is not None)
+        return out
+
+    @torch.no_grad()
+    def hidden_states_upto(self, input_ids, attention_mask, pixel_values=None, patch_embeddings=None, n_hidden: Optional[int] = None):
+        """Frozen-teacher fast path (mafed/methods/distillation.py:218-224): hidden_states[0 .. n_hidden-1] only --
+        the stack stops after layer n_hidden-2, no LM head, no saved activations."""
+        feats = patch_embeddings if patch_embeddings is not None else self.get_patch_embeddings(pixel_values)
+        dev = self.flat_params.device
+        st = self._engine_forward(feats.to(dev).contiguous(), input_ids.to(dev, torch.int64).contiguous(),
+                                  attention_mask.to(dev, torch.int64).contiguous(), None, True, train=False, n_hidden=n_hidden)
+        return tuple(st["hidden"])
+
+    # ---- engine ------------------------------------------------------------------------------------------------------
+    def _engine_forward(self, feats, input_ids, attention_mask, labels, want_hidden, train, n_hidden: Optional[int] = None):
+        if not self.flat_params.is_cuda:
+            raise RuntimeError("mafed_amd runs on the GPU only (no CPU fallback); move the model with .cuda()")
+        if self._shadow_dirty:
+            self.sync_shadow()
+        cfg, cd = self.config, self.compute_dtype
+        B, T = input_ids.shape
+        P, h, H, D, L = cfg.num_vision_tokens, cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers
+        S = P + T
+        rows = B * S
+        rot = cfg.rotary_ndims
+        cos, sin = self.rotary_tables(S)
+        w = self._w
+        sv: Dict[str, Any] = {"B": B, "T": T, "P": P, "S": S, "input_ids": input_ids, "attention_mask": attention_mask, "labels": labels,
+                              "layers": []}
+        # projector: Linear -> GELU(erf) -> Linear (vl_pythia.py:226-234,270)
+        f2 = feats.reshape(B * P, cfg.vision_hidden_size)
+        if f2.dtype not in (torch.float32, torch.bfloat16):
+            f2 = f2.float()
+        fc = f2.contiguous() if f2.dtype == cd else ops.cast(f2.contiguous(), cd)
+        u0 = torch.empty((B * P, h), dtype=cd, device=fc.device) if train else None
+        a0 = ops.gemm(fc, w("vision_embed_tokens.0.weight"), False, True, bias=self._p("vision_embed_tokens.0.bias"), epilogue=EPI_GELU, aux=u0)
+        img = ops.gemm(a0, w("vision_embed_tokens.2.weight"), False, True, bias=self._p("vision_embed_tokens.2.bias"))
+        x = ops.embed_concat_fwd(img, self._p("gpt_neox.embed_in.weight"), input_ids, B, P, T)  # fp32 residual stream
+        if train:
+            sv["proj"] = (fc, u0, a0)
+        hidden = [x]
+        n_layers = L if n_hidden is None else max(0, min(L, n_hidden - 1))
+        for i in range(n_layers):
+            pre = f"gpt_neox.layers.{i}."
+            ln1, ln2, mean, rstd = ops.layernorm_fwd(x, self._p(pre + "input_layernorm.weight"), self._p(pre + "input_layernorm.bias"),
+                                                     self._p(pre + "post_attention_layernorm.weight"), self._p(pre + "post_attention_layernorm.bias"),
+                                                     cfg.layer_norm_eps, cd, save_stats=train)
+            qkv = ops.gemm(ln1, w(pre + "attention.query_key_value.weight"), False, True, bias=self._p(pre + "attention.query_key_value.bias"))
+            ao, lse = ops.attn_fwd(qkv, B, S, H, D, rot, cos, sin, attention_mask)
+            attn = ops.gemm(ao, w(pre + "attention.dense.weight"), False, True, bias=self._p(pre + "attention.dense.bias"), out_dtype=torch.float32)
+            u = torch.empty((rows, cfg.intermediate_size), dtype=cd, device=x.device) if train else None
+            a = ops.gemm(ln2, w(pre + "mlp.dense_h_to_4h.weight"), False, True, bias=self._p(pre + "mlp.dense_h_to_4h.bias"), epilogue=EPI_GELU, aux=u)
+            # h + attn(LN1(h)) + mlp(LN2(h)) in the last GEMM's epilogue (tf:271-274)
+            xn = ops.gemm(a, w(pre + "mlp.dense_4h_to_h.weight"), False, True, bias=self._p(pre + "mlp.dense_4h_to_h.bias"),
+                          out_dtype=torch.float32, res1=attn, res2=x)
+            if train:
+                sv["layers"].append({"x": x, "mean": mean, "rstd": rstd, "ln1": ln1, "ln2": ln2, "qkv": qkv, "ao": ao, "lse": lse, "u": u, "a": a})
+            x = xn
+            if i < L - 1:
+                hidden.append(x)
+        sv["hidden"] = hidden
+        sv["loss"] = None
+        sv["logits"] = None
+        if n_hidden is not None:
+            return sv
+        # final LN (fp32 hidden state L only when asked for) + LM head on the T text positions (vl_pythia.py:89,310)
+        xt = x.view(B, S, h)[:, P:, :].reshape(B * T, h)
+        lnf, _, fmean, frstd = ops.layernorm_fwd(xt, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                                 None, None, cfg.layer_norm_eps, cd, save_stats=train)
+        if want_hidden:
+            full, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                              None, None, cfg.layer_norm_eps, torch.float32, save_stats=False)
+            hidden.append(full)
+        logits = ops.gemm(lnf, w("embed_out.weight"), False, True).view(B, T, cfg.vocab_size)
+        sv["logits"] = logits
+        if labels is not None:
+            loss, lse_ce = ops.ce_fwd(logits, labels)
+            sv["loss"] = loss
+            if train:
+                sv["ce_lse"] = lse_ce
+        if train:
+            sv["final"] = (xt, lnf, fmean, frstd)
+            sv["x_last"] = x
+        return sv
+
+    def hidden_grad_taps(self, batch: Dict[str, torch.Tensor], layers: Sequence[int]) -> Dict[int, torch.Tensor]:
+        """dL_CE / d hidden_states[l] for every l in ``layers`` from ONE backward sweep (the adaptive-weights pass of
+        mafed/methods/distillation_loss_weights.py:91-146 asks autograd for them one layer at a time)."""
+        feats = batch["patch_embeddings"] if "patch_embeddings" in batch else self.get_patch_embeddings(batch["pixel_values"])
+        dev = self.flat_params.device
+        sv = self._engine_forward(feats.to(dev).contiguous(), batch["input_ids"].to(dev, torch.int64).contiguous(),
+                                  batch["attention_mask"].to(dev, torch.int64).contiguous(),
+                                  batch["labels"].to(dev, torch.int64).contiguous(), False, train=True)
+        taps: Dict[int, torch.Tensor] = {int(l): None for l in layers}
+        self._engine_backward(sv, torch.ones(1, device=dev), [], taps=taps)
+        S = sv["S"]
+        return {l: t.view(sv["B"], S, -1) for l, t in taps.items()}
+
+    def _engine_backward(self, sv, dloss: Optional[torch.Tensor], dhidden: Sequence[Optional[torch.Tensor]], taps=None):
+        cfg, cd = self.config, self.compute_dtype
+        B, T, P, S = sv["B"], sv["T"], sv["P"], sv["S"]
+        h, H, D, L = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers
+        rows = B * S
+        rot = cfg.rotary_ndims
+        cos, sin = self.rotary_tables(S)
+        w, g = self._w, self._g
+        am = sv["attention_mask"]
+        dev = self.flat_params.device
+        if len(dhidden) > L and dhidden[L] is not None:
+            raise NotImplementedError("gradient w.r.t. the post-final-LayerNorm hidden state is not on the MAFED path")
+        dx = None  # gradient w.r.t. the residual stream leaving the current layer, fp32 [rows, h]
+        if dloss is not None and sv["loss"] is not None:
+            xt, lnf, fmean, frstd = sv["final"]
+            logits = sv["logits"]
+            gl = dloss.reshape(1).to(torch.float32).contiguous()
+            dlog = ops.ce_bwd(logits, sv["labels"], sv["ce_lse"], gl).view(B * T, cfg.vocab_size)
+            ops.gemm(dlog, lnf, True, False, out=g("embed_out.weight"), beta=1.0)
+            dlnf = ops.gemm(dlog, w("embed_out.weight"), False, False)
+            dxt, _ = ops.layernorm_bwd(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None,
+                                       g("gpt_neox.final_layer_norm.weight"), g("gpt_neox.final_layer_norm.bias"))
+            dx = torch.zeros((rows, h), dtype=torch.float32, device=dev)
+            dx.view(B, S, h)[:, P:, :] = dxt.view(B, T, h)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(L)
+        dy = None  # dx in compute dtype (GEMM operand)
+        for i in range(L - 1, -1, -1):
+            ext = dhidden[i + 1] if (i + 1) < min(len(dhidden), L) else None  # grad of hidden_states[i+1] = output of layer i
+            if ext is not None:
+                ext = ext.reshape(rows, h)
+                dx = ext.to(torch.float32) if dx is None else dx.add_(ext)
+                dy = None
+            if dx is None:
+                continue  # nothing flows into this layer's output (e.g. distillation of shallow layers only)
+            if dy is None:
+                dy = dx if cd == torch.float32 else ops.cast(dx, cd)
+            pre = f"gpt_neox.layers.{i}."
+            s = sv["layers"][i]
+            # MLP branch
+            ops.gemm(dy, s["a"], True, False, out=g(pre + "mlp.dense_4h_to_h.weight"), beta=1.0)
+            ops.colsum_(dy, g(pre + "mlp.dense_4h_to_h.bias"))
+            du = ops.gemm(dy, w(pre + "mlp.dense_4h_to_h.weight"), False, False, epilogue=EPI_GELU_BWD, aux=s["u"])
+            ops.gemm(du, s["ln2"], True, False, out=g(pre + "mlp.dense_h_to_4h.weight"), beta=1.0)
+            ops.colsum_(du, g(pre + "mlp.dense_h_to_4h.bias"))
+            dln2 = ops.gemm(du, w(pre + "mlp.dense_h_to_4h.weight"), False, False)
+            # attention branch
+            ops.gemm(dy, s["ao"], True, False, out=g(pre + "attention.dense.weight"), beta=1.0)
+            ops.colsum_(dy, g(pre + "attention.dense.bias"))
+            dao = ops.gemm(dy, w(pre + "attention.dense.weight"), False, False)
+            dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, S, H, D, rot, cos, sin, am)
+            ops.gemm(dqkv, s["ln1"], True, False, out=g(pre + "attention.query_key_value.weight"), beta=1.0)
+            ops.colsum_(dqkv, g(pre + "attention.query_key_value.bias"))
+            dln1 = ops.gemm(dqkv, w(pre + "attention.query_key_value.weight"), False, False)
+            # both LayerNorms + the residual path, one pass; also emits the compute-dtype copy the next layer's GEMMs read
+            dx, dy = ops.layernorm_bwd(dln1, dln2, s["x"], s["mean"], s["rstd"], self._p(pre + "input_layernorm.weight"),
+                                       self._p(pre + "post_attention_layernorm.weight"), dx,
+                                       g(pre + "input_layernorm.weight"), g(pre + "input_layernorm.bias"),
+                                       g(pre + "post_attention_layernorm.weight"), g(pre + "post_attention_layernorm.bias"),
+                                       want_lp=(cd != torch.float32))
+            if cd == torch.float32:
+                dy = dx
+            if taps is not None and i in taps:
+                taps[i] = dx  # = dL/d hidden_states[i] (fresh buffer, never written again on this path)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(i)
+        ext0 = dhidden[0] if len(dhidden) > 0 else None
+        if ext0 is not None:
+            ext0 = ext0.reshape(rows, h)
+            dx = ext0.to(torch.float32).contiguous() if dx is None else dx.add_(ext0)
+        if dx is not None:
+            fc, u0, a0 = sv["proj"]
+            dimg = ops.embed_concat_bwd(dx, sv["input_ids"], B, P, T, h, cfg.vocab_size, g("gpt_neox.embed_in.weight"), cd)
+            ops.gemm(dimg, a0, True, False, out=g("vision_embed_tokens.2.weight"), beta=1.0)
+            ops.colsum_(dimg, g("vision_embed_tokens.2.bias"))
+            du0 = ops.gemm(dimg, w("vision_embed_tokens.2.weight"), False, False, epilogue=EPI_GELU_BWD, aux=u0)
+            ops.gemm(du0, fc, True, False, out=g("vision_embed_tokens.0.weight"), beta=1.0)
+            ops.colsum_(du0, g("vision_embed_tokens.0.bias"))
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(-1)
+
+
+class _ModelFn(torch.autograd.Function):
+    """The whole model as one autograd node: outputs (loss, logits, *hidden_states)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model: VLPythiaForCausalLM, feats, input_ids, attention_mask, labels, want_hidden):
+        sv = model._engine_forward(feats, input_ids, attention_mask, labels, want_hidden, train=True)
+        ctx.model, ctx.sv = model, sv
+        loss = sv["loss"].reshape(()).clone() if sv["loss"] is not None else torch.zeros((), device=anchor.device)
+        outs = [loss, sv["logits"].detach()]
+        ctx.mark_non_differentiable(outs[1])
+        if want_hidden:
+            outs += [x.detach() for x in sv["hidden"]]  # aliases: no reference cycle through ctx
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dloss, dlogits, *dhidden):
+        sv = ctx.sv
+        ctx.sv = None
+        if sv is None:
+            raise RuntimeError("mafed_amd: backward through the model twice (activations already released)")
+        if sv["loss"] is None:
+            dloss = None
+        ctx.model._engine_backward(sv, dloss, list(dhidden))
+        return (None,) * 7
+
+
+model_architecture = {"vlpythia": VLPythiaForCausalLM}

@@ -1,0 +1,262 @@
+"""Thin tensor-level wrappers over the C-ABI (one Python function per entry point of include/mafed_hip.h).
+
+Every wrapper launches on torch's current HIP stream and never synchronises.  Tensors must live on the GPU;
+there is deliberately no CPU implementation behind these names.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from mafed_amd import _lib
+from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, F32, check  # noqa: F401
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise _lib.MafedHipError("mafed_amd ops need GPU tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """Grow-only scratch buffer handed to kernels that need one (no allocation inside the library)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+_workspaces = {}
+
+
+def workspace(device) -> Workspace:
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = Workspace(device)
+    return ws
+
+
+# bench.py's live roofline measurement: when a list is installed here every bf16 MFMA GEMM launch is bracketed by HIP
+# events on the launch stream and (start, end, flops) is appended (mafed_amd.ops.GEMM_EVENTS = []).
+GEMM_EVENTS = None
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Optional[torch.Tensor] = None,
+         out_dtype: Optional[torch.dtype] = None, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+         aux: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
+         beta: float = 0.0) -> torch.Tensor:
+    """C = op(A) @ op(B) with the fused epilogue of mafed_gemm.  A, B 2-D, same dtype (bf16 -> MFMA, f32 -> exact)."""
+    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N = B.shape[0] if transB else B.shape[1]
+    Kb = B.shape[1] if transB else B.shape[0]
+    assert K == Kb, (A.shape, B.shape, transA, transB)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    lib = _lib.load()
+    prof = GEMM_EVENTS is not None and A.dtype == torch.bfloat16
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mafed_gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
+                         out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream()),
+          "mafed_gemm")
+    if prof:
+        e1.record()
+        GEMM_EVENTS.append((e0, e1, 2.0 * M * N * K))
+    return out
+
+
+def colsum_(X: torch.Tensor, out: torch.Tensor) -> None:
+    """out[n] += sum_m X[m, n]"""
+    assert X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32
+    lib = _lib.load()
+    M, N = X.shape
+    nb = lib.mafed_colsum_workspace_bytes(M, N)
+    ws = workspace(X.device).get(nb)
+    check(lib.mafed_colsum(_ptr(X), _dt(X), M, N, X.stride(0), _ptr(out), _ptr(ws), ws.numel(), _stream()), "mafed_colsum")
+
+
+def layernorm_fwd(x: torch.Tensor, w1, b1, w2=None, b2=None, eps: float = 1e-5, out_dtype=torch.float32, save_stats: bool = True):
+    rows, h = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y1 = torch.empty((rows, h), dtype=out_dtype, device=x.device)
+    y2 = torch.empty_like(y1) if w2 is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(_lib.load().mafed_layernorm_fwd(_ptr(x), rows, h, eps, _ptr(w1), _ptr(b1), _ptr(y1), _ptr(w2), _ptr(b2), _ptr(y2),
+                                          _dt(y1), _ptr(mean), _ptr(rstd), _stream()), "mafed_layernorm_fwd")
+    return y1, y2, mean, rstd
+
+
+def layernorm_bwd(dy1, dy2, x, mean, rstd, w1, w2, dres, dw1, db1, dw2=None, db2=None, want_lp: bool = False,
+                  teacher=None, attention_mask=None, S: int = 0, P: int = 0, inj_scale=None):
+    rows, h = x.shape
+    dx = torch.empty((rows, h), dtype=torch.float32, device=x.device)
+    dx_lp = torch.empty((rows, h), dtype=dy1.dtype, device=x.device) if want_lp else None
+    lib = _lib.load()
+    nb = lib.mafed_layernorm_bwd_workspace_bytes(rows, h)
+    ws = workspace(x.device).get(nb)
+    check(lib.mafed_layernorm_bwd(_ptr(dy1), _ptr(dy2), _dt(dy1), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w1), _ptr(w2), rows, h,
+                                  _ptr(dres), _ptr(dx), _ptr(dx_lp), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(teacher),
+                                  _ptr(attention_mask), S, P, S - P, _ptr(inj_scale), _ptr(ws), ws.numel(), _stream()),
+          "mafed_layernorm_bwd")
+    return dx, dx_lp
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, D: int, rot: int, cos, sin, attention_mask: torch.Tensor):
+    T = attention_mask.shape[1]
+    out = torch.empty((B * S, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mafed_attn_fwd(_ptr(qkv), _dt(qkv), B, S, H, D, rot, _ptr(cos), _ptr(sin), _ptr(attention_mask), T, _ptr(out),
+                                     _ptr(lse), _stream()), "mafed_attn_fwd")
+    return out, lse
+
+
+def attn_fwd_exact_bf16(qkv, B, S, H, D, rot, cos, sin, attention_mask):
+    T = attention_mask.shape[1]
+    out = torch.empty((B * S, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mafed_attn_fwd_exact_bf16(_ptr(qkv), B, S, H, D, rot, _ptr(cos), _ptr(sin), _ptr(attention_mask), T, _ptr(out),
+                                                _ptr(lse), _stream()), "mafed_attn_fwd_exact_bf16")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, attention_mask):
+    T = attention_mask.shape[1]
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mafed_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _dt(qkv), B, S, H, D, rot, _ptr(cos), _ptr(sin),
+                                     _ptr(attention_mask), T, _ptr(dqkv), _ptr(delta), _stream()), "mafed_attn_bwd")
+    return dqkv
+
+
+def embed_concat_fwd(image: torch.Tensor, embed_in: torch.Tensor, input_ids: torch.Tensor, B: int, P: int, T: int) -> torch.Tensor:
+    V, h = embed_in.shape
+    h0 = torch.empty((B * (P + T), h), dtype=torch.float32, device=embed_in.device)
+    check(_lib.load().mafed_embed_concat_fwd(_ptr(image), _dt(image), _ptr(embed_in), _ptr(input_ids), B, P, T, h, V, _ptr(h0),
+                                             _stream()), "mafed_embed_concat_fwd")
+    return h0
+
+
+def embed_concat_bwd(dh0, input_ids, B, P, T, h, V, d_embed_in: Optional[torch.Tensor], img_dtype) -> torch.Tensor:
+    d_image = torch.empty((B * P, h), dtype=img_dtype, device=dh0.device)
+    check(_lib.load().mafed_embed_concat_bwd(_ptr(dh0), _ptr(input_ids), B, P, T, h, V, _ptr(d_image), _dt(d_image),
+                                             _ptr(d_embed_in), _stream()), "mafed_embed_concat_bwd")
+    return d_image
+
+
+def ce_fwd(logits: torch.Tensor, labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """logits [B,T,V] (text positions), labels [B,T] -> (loss[1], lse[B,T])"""
+    B, T, V = logits.shape
+    assert logits.is_contiguous() and labels.is_contiguous() and labels.dtype == torch.int64
+    lse = torch.empty((B, T), dtype=torch.float32, device=logits.device)
+    row_loss = torch.empty((B, T), dtype=torch.float32, device=logits.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    check(_lib.load().mafed_ce_fwd(_ptr(logits), _dt(logits), _ptr(labels), B, T, V, _ptr(lse), _ptr(row_loss), _ptr(loss), _stream()),
+          "mafed_ce_fwd")
+    return loss, lse
+
+
+def ce_bwd(logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, gloss: torch.Tensor,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dL/dlogits (pass out=logits for the in-place form)."""
+    B, T, V = logits.shape
+    if out is None:
+        out = torch.empty_like(logits)
+    check(_lib.load().mafed_ce_bwd(_ptr(logits), _dt(logits), _ptr(labels), _ptr(lse), B, T, V, _ptr(gloss), _ptr(out), _stream()),
+          "mafed_ce_bwd")
+    return out
+
+
+def distill_fwd(s: torch.Tensor, t: torch.Tensor, attention_mask: torch.Tensor, P: int, cosine: bool = False,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> out[4] = {lang_sum, vision_sum, n_lang, n_vision}"""
+    B, S, h = s.shape
+    assert s.dtype == torch.float32 and t.dtype == torch.float32 and s.is_contiguous() and t.is_contiguous()
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=s.device)
+    nb = lib.mafed_distill_workspace_bytes(B * S)
+    ws = workspace(s.device).get(nb)
+    check(lib.mafed_distill_fwd(_ptr(s), _ptr(t), _ptr(attention_mask), B, S, P, h, int(cosine), _ptr(out), _ptr(ws), ws.numel(),
+                                _stream()), "mafed_distill_fwd")
+    return out
+
+
+def distill_bwd(s, t, attention_mask, P: int, coef: torch.Tensor, cosine: bool = False, out: Optional[torch.Tensor] = None,
+                accumulate: bool = False) -> torch.Tensor:
+    B, S, h = s.shape
+    if out is None:
+        out = torch.empty_like(s)
+        accumulate = False
+    check(_lib.load().mafed_distill_bwd(_ptr(s), _ptr(t), _ptr(attention_mask), B, S, P, h, int(cosine), _ptr(coef), _ptr(out),
+                                        int(accumulate), _stream()), "mafed_distill_bwd")
+    return out
+
+
+def distill_cls_fwd(s, t) -> torch.Tensor:
+    B, S, h = s.shape
+    out = torch.empty(1, dtype=torch.float32, device=s.device)
+    check(_lib.load().mafed_distill_cls_fwd(_ptr(s), _ptr(t), B, S, h, _ptr(out), _stream()), "mafed_distill_cls_fwd")
+    return out
+
+
+def distill_cls_bwd(s, t, coef) -> torch.Tensor:
+    B, S, h = s.shape
+    out = torch.empty_like(s)
+    check(_lib.load().mafed_distill_cls_bwd(_ptr(s), _ptr(t), B, S, h, _ptr(coef), _ptr(out), 0, _stream()), "mafed_distill_cls_bwd")
+    return out
+
+
+def gradnorm_clip(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> out[2] = {||g||, clip scale}"""
+    lib = _lib.load()
+    if out2 is None:
+        out2 = torch.empty(2, dtype=torch.float32, device=g.device)
+    nb = lib.mafed_gradnorm_workspace_bytes(g.numel())
+    ws = workspace(g.device).get(nb)
+    check(lib.mafed_gradnorm_clip(_ptr(g), g.numel(), float(max_norm), _ptr(out2), _ptr(ws), ws.numel(), _stream()), "mafed_gradnorm_clip")
+    return out2
+
+
+def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None) -> None:
+    check(_lib.load().mafed_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
+                                       int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert src.is_contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.load().mafed_cast(_ptr(src), _dt(src), _ptr(out), _dt(out), src.numel(), _stream()), "mafed_cast")
+    return out
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty_like(x)
+    check(_lib.load().mafed_gelu(_ptr(x), _ptr(y), _dt(x), x.numel(), _stream()), "mafed_gelu")
+    return y
