@@ -53,7 +53,9 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
     batch = R.make_batch(cfg, B, T, seed=1235, pad=False)
     tr = R.RefTrainer(cfg, sd, lr=5e-5, accumulate=1, replay_interval=1, warmup_steps=0, total_steps=1000, task_id=1, teacher_sd=tsd,
                       spec=R.DistillSpec(modality="balanced", layer_strategy="discounted", gamma=0.5))
+    tw = time.time()
     tr.step(batch, 0, batch)  # warm-up
+    print(f"[bench] cpu baseline warm-up step {time.time() - tw:.1f} s on {cores} threads", file=sys.stderr, flush=True)
     n, t0 = 0, time.time()
     while n < 2 or (time.time() - t0 < seconds_hint and n < 8):
         tr.step(batch, n + 1, batch)
@@ -123,8 +125,16 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"setup done: {args.model} B={B} P={P} T={T} dtype={args.dtype} world={world}")
     for i in range(args.warmup):
+        tw = time.perf_counter()
         tr.step(task_batch, i)
+        torch.cuda.synchronize()
+        log(f"warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     torch.cuda.synchronize()
     barrier()
     if rank == 0 and not args.no_gemm_events:
@@ -141,6 +151,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss = float(rec["loss"])
+    log(f"timed region: {args.steps} steps in {dt * 1e3:.1f} ms, loss {loss:.5f}")
     assert loss == loss, "NaN loss in the timed region"
 
     if rank == 0:

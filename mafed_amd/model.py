@@ -404,7 +404,7 @@ class VLPythiaForCausalLM(nn.Module):
         x = ops.embed_concat_fwd(img, self._p("gpt_neox.embed_in.weight"), input_ids, B, P, T)  # fp32 residual stream
         if train:
             sv["proj"] = (fc, u0, a0)
-        hidden = [x]
+        hidden = [x.view(B, S, h)]
         n_layers = L if n_hidden is None else max(0, min(L, n_hidden - 1))
         for i in range(n_layers):
             pre = f"gpt_neox.layers.{i}."
@@ -423,7 +423,7 @@ class VLPythiaForCausalLM(nn.Module):
                 sv["layers"].append({"x": x, "mean": mean, "rstd": rstd, "ln1": ln1, "ln2": ln2, "qkv": qkv, "ao": ao, "lse": lse, "u": u, "a": a})
             x = xn
             if i < L - 1:
-                hidden.append(x)
+                hidden.append(x.view(B, S, h))
         sv["hidden"] = hidden
         sv["loss"] = None
         sv["logits"] = None
@@ -436,7 +436,7 @@ class VLPythiaForCausalLM(nn.Module):
         if want_hidden:
             full, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
                                               None, None, cfg.layer_norm_eps, torch.float32, save_stats=False)
-            hidden.append(full)
+            hidden.append(full.view(B, S, h))
         logits = ops.gemm(lnf, w("embed_out.weight"), False, True).view(B, T, cfg.vocab_size)
         sv["logits"] = logits
         if labels is not None:
@@ -551,6 +551,7 @@ class _ModelFn(torch.autograd.Function):
     def forward(ctx, anchor, model: VLPythiaForCausalLM, feats, input_ids, attention_mask, labels, want_hidden):
         sv = model._engine_forward(feats, input_ids, attention_mask, labels, want_hidden, train=True)
         ctx.model, ctx.sv = model, sv
+        ctx.set_materialize_grads(False)  # outputs nobody differentiated arrive as None, not as zero tensors
         loss = sv["loss"].reshape(()).clone() if sv["loss"] is not None else torch.zeros((), device=anchor.device)
         outs = [loss, sv["logits"].detach()]
         ctx.mark_non_differentiable(outs[1])
