@@ -44,12 +44,25 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
     """The oracle (CPU restatement of the reference path, fp32 eager) timed on this box's host cores on a bounded sample
     of the same workload: same model / sequence shape / MAFED step, batch 4 instead of 32."""
     from oracle import vlpythia_ref as R
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's CPU share (16 threads); os.cpu_count() reports the whole host and oversubscribes
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     B = 4
     cfg = R.preset(model_name, num_vision_tokens=P)
-    sd = R.init_weights(cfg, seed=1234)
-    tsd = {k: v + 1e-3 * torch.randn(v.shape, generator=torch.Generator().manual_seed(1237)) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(1234)
+    sd = {}
+    for name, shape in R.param_shapes(cfg):  # HF init distribution; same shapes/names as the GPU run
+        if "layernorm" in name or "layer_norm" in name:
+            sd[name] = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+        elif name.endswith("bias"):
+            sd[name] = torch.zeros(shape)
+        else:
+            sd[name] = torch.randn(shape, generator=g) * 0.02
+    tsd = {k: v + 1e-3 * torch.randn(v.shape, generator=g) for k, v in sd.items()}
     batch = R.make_batch(cfg, B, T, seed=1235, pad=False)
     tr = R.RefTrainer(cfg, sd, lr=5e-5, accumulate=1, replay_interval=1, warmup_steps=0, total_steps=1000, task_id=1, teacher_sd=tsd,
                       spec=R.DistillSpec(modality="balanced", layer_strategy="discounted", gamma=0.5))

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mafed_version": (_i, []),
     "mafed_last_error_string": (C.c_char_p, []),
     "mafed_gemm": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p]),
+    "mafed_gemm_set_variant": (_i, [_i]),
     "mafed_colsum_workspace_bytes": (_z, [_l, _l]),
     "mafed_colsum": (_i, [_p, _i, _l, _l, _l, _p, _p, _z, _p]),
     "mafed_layernorm_fwd": (_i, [_p, _l, _i, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),

@@ -209,6 +209,148 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(int64_t M, int64_t N,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, LDS-DMA staging (global_load_lds_dwordx4): the fast path for tile-aligned shapes.
+// Block tile (WM*64) x (WN*64) x 64, WM*WN waves of 64x64.  Operand tiles go global -> LDS without touching VGPRs
+// (ds_write_b128 staging tops out near 79 B/clk/CU and was the v1 bottleneck); the LDS images and their swizzles
+// are those of the register-staged kernel -- the DMA writes LDS linearly, so the XOR is applied to each lane's
+// SOURCE address (cdna_hip_programming rule 21).  Two LDS stages, one barrier per K-tile: the DMA of tile t+1 is
+// issued right after the barrier that publishes tile t and flies under tile t's MFMAs.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// per-lane source element offset (without the k-tile advance) of DMA instruction j of an R-row operand tile
+template <bool KS, int R>
+__device__ __forceinline__ int64_t glds_src_off(int j, int lane, int64_t ld, int64_t r0) {
+  if (!KS) {
+    const int row = j * 8 + (lane >> 3), phys = lane & 7;
+    const int logical = phys ^ ((row >> 1) & 7);
+    return (r0 + row) * ld + logical * 8;
+  } else {
+    constexpr int RB = 2 * R;                  // bytes per k-row of the image
+    const int p = j * 1024 + lane * 16;
+    const int k = p / RB, within = p % RB;
+    const int logical16 = (within >> 5) ^ ks_f(k);
+    return (int64_t)k * ld + r0 + logical16 * 16 + ((within >> 4) & 1) * 8;
+  }
+}
+template <int R>
+__device__ __forceinline__ int lds_off_ks_r(int k, int r16, int byte_in_32) { return k * (2 * R) + ((r16 ^ ks_f(k)) << 5) + byte_in_32; }
+
+template <bool KS, int R>
+__device__ __forceinline__ bf16x8 glds_read_frag(const char* __restrict__ img, int rt, int ks, int lane) {
+  if (!KS) {
+    const int row = rt * 16 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(img + lds_off_kc(row, ks * 4 + (lane >> 4)));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int ka = ks * 32 + 8 * g + q, kb = ka + 4;
+    typedef __attribute__((address_space(3))) bf16x4* lptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks_r<R>(ka, rt, p * 8)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks_r<R>(kb, rt, p * 8)));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <int WM, int WN, bool A_KS, bool B_KS, typename CT>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
+                                                                       int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                                       CT* __restrict__ C, GemmEpi epi, int tiles_n, int nwg) {
+  constexpr int TM = WM * 64, TN = WN * 64, NW = WM * WN;
+  constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PER_WAVE = TM / 8 / NW, B_PER_WAVE = TN / 8 / NW;  // 1 KiB DMA instructions per wave per K-tile
+  static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1, "tile too small for the wave count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int64_t m0 = (int64_t)(bid / tiles_n) * TM, n0 = (int64_t)(bid % tiles_n) * TN;
+
+  // per-lane DMA sources; k-tile advance is +64 elements (KC) or +64 rows (KS)
+  const bf16_t* asrc[A_PER_WAVE];
+  const bf16_t* bsrc[B_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] = A + glds_src_off<A_KS, TM>(wave * A_PER_WAVE + i, lane, lda, m0);
+#pragma unroll
+  for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] = B + glds_src_off<B_KS, TN>(wave * B_PER_WAVE + i, lane, ldb, n0);
+  const int64_t a_step = A_KS ? 64 * lda : 64, b_step = B_KS ? 64 * ldb : 64;
+
+  auto issue = [&](int stage, int kt) {
+    char* sa = smem + stage * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[i] + kt * a_step), (lds_void_ptr)(sa + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + kt * b_step), (lds_void_ptr)(sb + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (int)(K / BK);
+  issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
+    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+    const char* sa = smem + (kt & 1) * STAGE;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = glds_read_frag<A_KS, TM>(sa, wm * 4 + t, ks, lane);
+        fb[t] = glds_read_frag<B_KS, TN>(sb, wn * 4 + t, ks, lane);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int64_t n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+      epilogue_store4<CT>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
+    }
+  }
+}
+
+template <int WM, int WN, bool A_KS, bool B_KS, typename CT>
+static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                            const GemmEpi& epi, hipStream_t st) {
+  constexpr int TM = WM * 64, TN = WN * 64, LDS = 2 * (TM + TN) * 128;
+  const int64_t tm = M / TM, tn = N / TN, nwg = tm * tn;
+  if (nwg > 0x7fffffff) { set_error("gemm: grid too large"); return MAFED_EINVAL; }
+  auto kfn = gemm_bf16_glds_kernel<WM, WN, A_KS, B_KS, CT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  kfn<<<dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi, (int)tn,
+                                                             (int)nwg);
+  return MAFED_OK;
+}
+
 template <bool A_KS, bool B_KS, typename CT>
 static int launch_bf16(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                        const GemmEpi& epi, hipStream_t st) {
@@ -229,6 +371,10 @@ static int launch_bf16(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
 }  // namespace mafed
 
 using namespace mafed;
+
+// test / tuning hook: 0 = automatic, 1 = force the register-staged kernel
+static int g_gemm_variant = 0;
+extern "C" int mafed_gemm_set_variant(int v) { g_gemm_variant = v; return MAFED_OK; }
 
 extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                           const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
@@ -261,6 +407,20 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
                   (long long)M, (long long)K, transB, (long long)N);
   const bool a_ks = transA != 0, b_ks = transB == 0;
   int rc;
+  const bool aligned = (M % 128 == 0) && (N % 128 == 0) && (K % 64 == 0) && g_gemm_variant != 1;
+  if (aligned) {
+#define GOG(AKS, BKS)                                                                                              \
+  rc = (c_dtype == MAFED_F32) ? launch_bf16_glds<2, 2, AKS, BKS, float>(M, N, K, A, lda, B, ldb, C, epi, st)       \
+                              : launch_bf16_glds<2, 2, AKS, BKS, bf16_t>(M, N, K, A, lda, B, ldb, C, epi, st)
+    if (!a_ks && !b_ks) GOG(false, false);
+    else if (!a_ks && b_ks) GOG(false, true);
+    else if (a_ks && b_ks) GOG(true, true);
+    else GOG(true, false);
+#undef GOG
+    if (rc != MAFED_OK) return rc;
+    MAFED_CHECK_LAUNCH("gemm(bf16, lds-dma)");
+    return MAFED_OK;
+  }
 #define GO(AKS, BKS)                                                                                         \
   rc = (c_dtype == MAFED_F32) ? launch_bf16<AKS, BKS, float>(M, N, K, A, lda, B, ldb, C, epi, st)            \
                               : launch_bf16<AKS, BKS, bf16_t>(M, N, K, A, lda, B, ldb, C, epi, st)

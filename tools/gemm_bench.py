@@ -1,0 +1,56 @@
+"""Micro-benchmark of the bf16 MFMA GEMM on the shapes of the 410M MAFED step (run on the GPU box).
+Interleaved rounds in one process (cdna_hip_programming rule 24), random data (rule 25)."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mafed_amd import ops, _lib
+
+dev = "cuda"
+M = 9216
+SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
+    ("qkv   NT", False, True, M, 3072, 1024, torch.bfloat16),
+    ("dense NT", False, True, M, 1024, 1024, torch.float32),
+    ("fc1   NT", False, True, M, 4096, 1024, torch.bfloat16),
+    ("fc2   NT", False, True, M, 1024, 4096, torch.float32),
+    ("dfc2  NN", False, False, M, 4096, 1024, torch.bfloat16),
+    ("dfc1  NN", False, False, M, 1024, 4096, torch.bfloat16),
+    ("dqkv  NN", False, False, M, 1024, 3072, torch.bfloat16),
+    ("wfc2  TN", True, False, 1024, 4096, M, torch.float32),
+    ("wfc1  TN", True, False, 4096, 1024, M, torch.float32),
+    ("wqkv  TN", True, False, 3072, 1024, M, torch.float32),
+    ("wdns  TN", True, False, 1024, 1024, M, torch.float32),
+    ("head  NT", False, True, 1024, 50304, 1024, torch.bfloat16),
+]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
+lib = _lib.load()
+g = torch.Generator(device=dev).manual_seed(0)
+res = {}
+for name, tA, tB, m, n, k, od in SHAPES:
+    A = torch.randn((k, m) if tA else (m, k), device=dev, generator=g).to(torch.bfloat16)
+    B = torch.randn((n, k) if tB else (k, n), device=dev, generator=g).to(torch.bfloat16)
+    out = torch.zeros((m, n), dtype=od, device=dev)
+    ref = None
+    for v in variants:
+        lib.mafed_gemm_set_variant(v)
+        ops.gemm(A, B, tA, tB, out=out)
+        if ref is None:
+            ref = out.float().clone()
+        else:
+            err = (out.float() - ref).abs().max().item()
+            assert err <= 1e-2 * ref.abs().max().item(), (name, v, err)
+    times = {v: [] for v in variants}
+    for rnd in range(5):
+        for v in variants:
+            lib.mafed_gemm_set_variant(v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.gemm(A, B, tA, tB, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 10)
+    fl = 2.0 * m * n * k
+    line = f"{name} {m}x{n}x{k}: " + "  ".join(f"v{v}: {min(t)*1e3:7.1f} us {fl/min(t)/1e9:7.1f} TF" for v, t in times.items())
+    print(line, flush=True)
+lib.mafed_gemm_set_variant(0)
