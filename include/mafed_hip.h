@@ -59,7 +59,8 @@ int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t 
                const float* bias, int epilogue, void* aux,
                const float* res1, const float* res2, float beta, void* stream);
 
-/* out[n] += sum_m X[m,n]   (bias gradients; X dtype bf16/f32, out fp32 accumulate).  workspace: >= colsum_workspace_bytes */
+/* out[n] += sum_m X[m,n]   (bias gradients; X dtype bf16/f32, out fp32 accumulated with one atomic per column per
+ * 256-row block; N, ldx multiples of 4).  workspace is unused (kept for ABI stability; workspace_bytes may be 0). */
 size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N);
 int mafed_colsum(const void* X, mafed_dtype dtype, int64_t M, int64_t N, int64_t ldx, float* out,
                  void* workspace, size_t workspace_bytes, void* stream);
@@ -154,11 +155,19 @@ int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, float* out2, 
 /* HF-style AdamW on a flat segment (mafed/optim/adamw.py:86-111): m,v update; denom = sqrt(v) + eps (not bias
  * corrected); p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/denom; then p -= lr*wd*p.  g is multiplied by clip_scale_dev[1]
  * (from mafed_gradnorm_clip) and by grad_mul (1/world for DDP means).  lr_dev: device scalar (scheduled lr).
+ * step >= 1: bias corrections computed on the host from step (double).  step == 0: lr_dev points at three floats
+ * {lr, 1-b1^t, sqrt(1-b2^t)} that the host refreshes before each launch -- the form a hipGraph replay needs.
  * If p_bf16 != NULL also writes the bf16 shadow copy used by the MFMA GEMMs.  The host keeps decayed and
  * non-decayed parameters in two contiguous segments of the flat buffer and calls this once per segment. */
 int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
                      float eps, float weight_decay, int step, const float* clip_dev /* out2 of gradnorm or NULL */,
                      float grad_mul, void* p_bf16, void* stream);
+
+/* Device-resident schedule (mafed/optim/sched.py:34-48 + the bias corrections of adamw.py:94-97): state_dev[0] = number of
+ * optimiser steps taken so far; increments it to t and writes hyper3_dev = {base_lr * lambda(t-1), 1-b1^t, sqrt(1-b2^t)}
+ * (double precision inside) for mafed_adamw_step(step = 0).  total_steps <= 0 means a constant learning rate. */
+int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1, double beta2,
+                        float* hyper3_dev, void* stream);
 
 /* ---- small utilities --------------------------------------------------------------------------------------------- */
 int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype dst_dtype, int64_t n, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmafed_hip.so")
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
 
-_p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_p, _i, _l, _f, _z, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); mirrors include/mafed_hip.h one to one
 SIGNATURES = {
@@ -42,6 +42,7 @@ SIGNATURES = {
     "mafed_gradnorm_workspace_bytes": (_z, [_l]),
     "mafed_gradnorm_clip": (_i, [_p, _l, _f, _p, _p, _z, _p]),
     "mafed_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
+    "mafed_optim_advance": (_i, [_p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_gelu": (_i, [_p, _p, _i, _l, _p]),
 }

@@ -108,8 +108,33 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
   return cdf + x * pdf;
+}
+
+// Fast erf-GELU for the bf16 MFMA epilogues (Abramowitz-Stegun 7.1.26, |err(erf)| <= 1.5e-7; one v_exp + one v_rcp):
+// the libm erff costs more VALU time than the MFMA main loop leaves idle.  exp(-z^2) with z = x/sqrt(2) is also the
+// Gaussian of gelu', so the derivative needs no second exponential.  The fp32 parity path keeps erff.
+__device__ __forceinline__ void erf_gauss_fast(float x, float& erf_z, float& gauss) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  gauss = __expf(-z * z);  // = exp(-x^2 / 2)
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * gauss;
+  erf_z = copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  float e, g;
+  erf_gauss_fast(x, e, g);
+  return 0.5f * x * (1.0f + e);
+}
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  float e, g;
+  erf_gauss_fast(x, e, g);
+  return 0.5f * (1.0f + e) + x * 0.39894228040143267794f * g;
 }
 
 // modality class of a token row (mafed/methods/distillation.py:134-144): 0 = language (valid text), 1 = vision, 2 = none (pad)

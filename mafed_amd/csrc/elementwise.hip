@@ -69,35 +69,34 @@ __global__ __launch_bounds__(256) void embed_concat_bwd_kernel(const float* __re
   }
 }
 
-// stage 1: partial[blk][n] = sum over the block's row slice; stage 2 sums the partials and accumulates into out.
-constexpr int CS_ROWS = 64;  // rows per block slice (x 4 row-groups of threads)
+// out[n] += sum_m X[m,n].  Block = 256 rows x 128 columns: 32 column-quads x 8 row-groups of threads, 8/16-byte
+// loads, LDS tree over the row groups, then ONE fp32 atomic per column per block (M/256 adders per address, spread
+// over N addresses -- far from the contended regime of MI355X_MICROARCH "Global float atomics").
+constexpr int CS_ROWS = 256, CS_COLS = 128;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx,
-                                                             float* __restrict__ partial) {
-  __shared__ float sm[4][64];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 64 + col;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ldx, float* __restrict__ out) {
+  __shared__ float4 sm[8][32];
+  const int cq = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int64_t n = (int64_t)blockIdx.x * CS_COLS + cq * 4;
   const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
-  float s = 0.f;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < N) {
     const int64_t m1 = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
-    for (int64_t m = m0 + grp; m < m1; m += 4) s += Elem<T>::load(X + m * ldx + n);
+    for (int64_t m = m0 + rg; m < m1; m += 8) {
+      const float4 v = load4(X + m * ldx + n);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  sm[grp][col] = s;
+  sm[rg][cq] = s;
   __syncthreads();
-  if (grp == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t nslice, int64_t N,
-                                                           float* __restrict__ out) {
-  __shared__ float sm[4][64];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 64 + col;
-  float s = 0.f;
-  if (n < N)
-    for (int64_t b = grp; b < nslice; b += 4) s += partial[b * N + n];
-  sm[grp][col] = s;
-  __syncthreads();
-  if (grp == 0 && n < N) out[n] += (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
+  if (rg == 0 && n < N) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const float4 v = sm[r][cq];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    atomicAdd(out + n, s.x); atomicAdd(out + n + 1, s.y); atomicAdd(out + n + 2, s.z); atomicAdd(out + n + 3, s.w);
+  }
 }
 
 static int grid_for(int64_t n, int per_thread = 1) {
@@ -164,23 +163,18 @@ extern "C" int mafed_embed_concat_bwd(const float* dh0, const int64_t* input_ids
   return MAFED_OK;
 }
 
-extern "C" size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N) { return (size_t)cdiv(M, CS_ROWS) * (size_t)N * sizeof(float); }
+extern "C" size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N) { (void)M; (void)N; return 0; }
 
 extern "C" int mafed_colsum(const void* X, mafed_dtype dtype, int64_t M, int64_t N, int64_t ldx, float* out, void* workspace,
                             size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
   MAFED_CHECK_ARG(X && out && M >= 0 && N > 0 && ldx >= N, "colsum: bad arguments");
+  MAFED_CHECK_ARG(N % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 7) == 0, "colsum: N and ldx must be multiples of 4, X 8-byte aligned");
   if (M == 0) return MAFED_OK;
-  const int64_t nslice = cdiv(M, CS_ROWS);
-  if (!workspace || workspace_bytes < (size_t)nslice * N * sizeof(float)) {
-    set_error("colsum: workspace %zu < %zu", workspace_bytes, (size_t)nslice * N * sizeof(float));
-    return MAFED_EWORKSPACE;
-  }
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)cdiv(N, 64), (unsigned)nslice), block(256);
-  if (dtype == MAFED_F32) colsum_partial_kernel<float><<<grid, block, 0, st>>>((const float*)X, M, N, ldx, (float*)workspace);
-  else colsum_partial_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)X, M, N, ldx, (float*)workspace);
-  MAFED_CHECK_LAUNCH("colsum(partial)");
-  colsum_final_kernel<<<dim3((unsigned)cdiv(N, 64)), block, 0, st>>>((const float*)workspace, nslice, N, out);
-  MAFED_CHECK_LAUNCH("colsum(final)");
+  dim3 grid((unsigned)cdiv(N, CS_COLS), (unsigned)cdiv(M, CS_ROWS)), block(256);
+  if (dtype == MAFED_F32) colsum_kernel<float><<<grid, block, 0, st>>>((const float*)X, M, N, ldx, out);
+  else colsum_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)X, M, N, ldx, out);
+  MAFED_CHECK_LAUNCH("colsum");
   return MAFED_OK;
 }

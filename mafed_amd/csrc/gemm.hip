@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(int64_t M, int64_t N,
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int64_t n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-      if (n < N) epilogue_store4<CT>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
+      if (n < N) epilogue_store4<CT, true>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
     }
   }
 }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int64_t n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-      epilogue_store4<CT>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
+      epilogue_store4<CT, true>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
     }
   }
 }

@@ -15,7 +15,7 @@ struct GemmEpi {
 };
 
 // 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N guaranteed by the caller)
-template <typename CT>
+template <typename CT, bool FAST = false>
 __device__ __forceinline__ void epilogue_store4(const GemmEpi& e, CT* __restrict__ C, int64_t m, int64_t n, float4 v) {
   const int64_t off = m * e.ldc + n;
   if (e.bias) {
@@ -24,10 +24,12 @@ __device__ __forceinline__ void epilogue_store4(const GemmEpi& e, CT* __restrict
   }
   if (e.mode == MAFED_EPI_GELU) {
     if (e.aux) store4(reinterpret_cast<CT*>(e.aux) + off, v);
-    v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    if (FAST) v = make_float4(gelu_erf_fast(v.x), gelu_erf_fast(v.y), gelu_erf_fast(v.z), gelu_erf_fast(v.w));
+    else v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
   } else if (e.mode == MAFED_EPI_GELU_BWD) {
     const float4 u = load4(reinterpret_cast<const CT*>(e.aux) + off);
-    v = make_float4(v.x * gelu_erf_grad(u.x), v.y * gelu_erf_grad(u.y), v.z * gelu_erf_grad(u.z), v.w * gelu_erf_grad(u.w));
+    if (FAST) v = make_float4(v.x * gelu_erf_grad_fast(u.x), v.y * gelu_erf_grad_fast(u.y), v.z * gelu_erf_grad_fast(u.z), v.w * gelu_erf_grad_fast(u.w));
+    else v = make_float4(v.x * gelu_erf_grad(u.x), v.y * gelu_erf_grad(u.y), v.z * gelu_erf_grad(u.z), v.w * gelu_erf_grad(u.w));
   }
   if (e.res1) {
     const float4 r = load4(e.res1 + off);

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                                                     const float* __restrict__ clip_dev, float grad_mul, bf16_t* __restrict__ p_bf16) {
   const float lr = lr_dev[0];
+  if (bc1 <= 0.f) {  // hyper-parameters of this step live in device memory (hipGraph replay): {lr, 1-b1^t, sqrt(1-b2^t)}
+    bc1 = lr_dev[1];
+    bc2_sqrt = lr_dev[2];
+  }
   const float gs = grad_mul * (clip_dev ? clip_dev[1] : 1.0f);
   const float step_size = lr * bc2_sqrt / bc1;
   const float decay = lr * wd;
@@ -81,9 +85,40 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// One thread: advance the optimiser step counter and publish this step's scalars {lr, 1-b1^t, sqrt(1-b2^t)} in double
+// precision, so that a whole training step (schedule included) replays from a hipGraph without host involvement.
+__global__ void optim_advance_kernel(long long* __restrict__ state, double base_lr, long long warmup, long long total, double b1,
+                                     double b2, float* __restrict__ hyper) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t = state[0] + 1;
+  state[0] = t;
+  const long long s = t - 1;  // LambdaLR epoch in force during optimiser step t (scheduler steps once per optimiser step)
+  double lam = 1.0;
+  if (total > 0) {
+    if (s < warmup) lam = (double)s / (double)(warmup > 1 ? warmup : 1);
+    else {
+      const long long den = total - warmup > 1 ? total - warmup : 1;
+      lam = (double)(total - s) / (double)den;
+      if (lam < 0.0) lam = 0.0;
+    }
+  }
+  hyper[0] = (float)(base_lr * lam);
+  hyper[1] = (float)(1.0 - pow(b1, (double)t));
+  hyper[2] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+
 }  // namespace mafed
 
 using namespace mafed;
+
+extern "C" int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1,
+                                   double beta2, float* hyper3_dev, void* stream) {
+  MAFED_CHECK_ARG(state_dev && hyper3_dev, "optim_advance: null pointer");
+  optim_advance_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>((long long*)state_dev, base_lr, (long long)warmup_steps,
+                                                                    (long long)total_steps, beta1, beta2, hyper3_dev);
+  MAFED_CHECK_LAUNCH("optim_advance");
+  return MAFED_OK;
+}
 
 extern "C" size_t mafed_gradnorm_workspace_bytes(int64_t n) { (void)n; return (size_t)GN_BLOCKS * sizeof(float); }
 
@@ -109,13 +144,14 @@ extern "C" int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, fl
 extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
                                 float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
                                 void* stream) {
-  MAFED_CHECK_ARG(p && g && m && v && lr_dev && n >= 0 && step >= 1, "adamw_step: bad arguments");
+  MAFED_CHECK_ARG(p && g && m && v && lr_dev && n >= 0 && step >= 0, "adamw_step: bad arguments");
   MAFED_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step: buffers must be 16-byte aligned");
   MAFED_CHECK_ARG(!p_bf16 || ((uintptr_t)p_bf16 & 7) == 0, "adamw_step: p_bf16 must be 8-byte aligned");
   if (n == 0) return MAFED_OK;
   // bias corrections in double on the host, exactly as math.sqrt(1 - b2**t) / (1 - b1**t) (adamw.py:94-97)
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  // step == 0: the kernel reads {lr, 1-b1^t, sqrt(1-b2^t)} from lr_dev[0..2] (graph-replayable form)
+  const double bc1 = step > 0 ? 1.0 - pow((double)beta1, (double)step) : 0.0;
+  const double bc2 = step > 0 ? 1.0 - pow((double)beta2, (double)step) : 0.0;
   hipStream_t st = as_stream(stream);
   int64_t nb = cdiv(n / 4 + 1, 256);
   if (nb > 4096) nb = 4096;

@@ -93,6 +93,8 @@ class FeatureDistillation(CLStrategy):
         self.opts = opts
         self.num_vision_tokens = 256  # hard-coded upstream (distillation.py:73); instance attribute, settable
         self.mem_dataloader = None
+        self.overlap_teacher = True
+        self._prefetched = None
         self.last_layer_losses: Optional[torch.Tensor] = None  # [n_layers] device tensor of the last distill() call
         self.last_modality_losses: Optional[torch.Tensor] = None  # [n_layers, 2] (lang, vision)
 
@@ -156,6 +158,8 @@ class FeatureDistillation(CLStrategy):
         batch = next(iter(self.mem_dataloader))
         n_ex = batch["input_ids"].size(0)
         do_replay = self.replay_coeff > 0 and self.task_id > 0
+        if self.distillation_coeff != 0:
+            self._prefetch_teacher(batch)  # frozen-teacher forward on a second HIP stream, concurrent with the student's
         output = model(**batch, compute_loss=do_replay, output_hidden_states=True, return_dict=True)
         loss = self.replay_coeff * output.loss if do_replay else None
         if self.distillation_coeff == 0:
@@ -164,9 +168,33 @@ class FeatureDistillation(CLStrategy):
         loss = dloss if loss is None else loss + dloss
         return loss, n_ex
 
+    def _prefetch_teacher(self, batch):
+        """Issue the teacher forward on its own stream before the student's (same arithmetic, earlier in time): the two
+        forwards are independent kernel chains, so their wave-quantisation tails fill each other on the 256 CUs."""
+        self._prefetched = None
+        pm = self.past_model
+        if not (self.overlap_teacher and hasattr(pm, "hidden_states_upto") and pm.flat_params.is_cuda):
+            return
+        layers = self.loss_weights.get_distillation_layers()
+        main = torch.cuda.current_stream()
+        side = pm.side_stream()
+        side.wait_stream(main)  # everything of the previous step (which may still read last step's teacher states) is ordered first
+        kw = {"patch_embeddings": batch["patch_embeddings"]} if "patch_embeddings" in batch else {"pixel_values": batch["pixel_values"]}
+        with torch.cuda.stream(side):
+            hs = [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=max(layers) + 1, **kw)]
+            ev = side.record_event()
+        self._prefetched = (hs, ev, max(layers) + 1)
+
     def _get_past_hidden_states(self, batch, n_hidden: Optional[int] = None):
         """Frozen-teacher hidden states; pops ``labels`` from the caller's dict like upstream (distillation.py:218-224)."""
         batch.pop("labels", None)
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None:
+            self._prefetched = None
+            hs, ev, n = pre
+            if n_hidden is None or n >= n_hidden:
+                torch.cuda.current_stream().wait_event(ev)
+                return hs
         pm = self.past_model
         with torch.no_grad():
             if hasattr(pm, "hidden_states_upto"):

@@ -15,6 +15,7 @@ class DistillationWeights:
                  distillation_layer_weighing_strategy: str = "single", gamma: float = 0.9, num_hidden_layers: int = 11,
                  distillation_layer: Optional[int] = -1, num_vision_tokens: int = 256) -> None:
         self.gamma = gamma
+        self._dev_cache = {}
         self.num_vision_tokens = num_vision_tokens
         self._hidden_state_layer = distillation_layer
         self._modality_weighing_strategy = distillation_modality_weighing_strategy
@@ -55,11 +56,18 @@ class DistillationWeights:
         return self.layer_coeffs[layer]
 
     def layer_coeff_vector(self, device) -> torch.Tensor:
-        """Coefficients of get_distillation_layers(), as one fp32 device vector."""
-        layers = self.get_distillation_layers()
-        if self.layer_coeffs is None or self._layer_weighing_strategy == "single":
-            return torch.ones(len(layers), dtype=torch.float32, device=device)
-        return self.layer_coeffs[layers].to(device=device, dtype=torch.float32)
+        """Coefficients of get_distillation_layers(), as one fp32 device vector (uploaded once: the per-step path must
+        not copy from the host, it is replayed from a hipGraph)."""
+        key = ("coeff", str(device))
+        v = self._dev_cache.get(key)
+        if v is None:
+            layers = self.get_distillation_layers()
+            if self.layer_coeffs is None or self._layer_weighing_strategy == "single":
+                v = torch.ones(len(layers), dtype=torch.float32, device=device)
+            else:
+                v = self.layer_coeffs[layers].to(device=device, dtype=torch.float32)
+            self._dev_cache[key] = v
+        return v
 
     # ---- modalities -------------------------------------------------------------------------------------------------
     def get_modality_loss_weights(self, batch, layer: int):
@@ -82,10 +90,17 @@ class DistillationWeights:
         if s == "equal":
             lw = (n_lang / (n_lang + n_vision)).expand(nl)
         elif s == "balanced":
-            lw = torch.full((nl,), float(self.lang_coeff), dtype=torch.float32, device=device)
+            key = ("balanced", str(device), nl, float(self.lang_coeff))
+            lw = self._dev_cache.get(key)
+            if lw is None:
+                lw = self._dev_cache[key] = torch.full((nl,), float(self.lang_coeff), dtype=torch.float32, device=device)
         elif s == "adaptive":
-            lc = torch.as_tensor(self.lang_coeff, dtype=torch.float32, device=device).reshape(-1)
-            lw = lc.expand(nl) if lc.shape[0] == 1 else lc[torch.as_tensor(list(layers), device=device)]
+            key = ("adaptive", str(device), tuple(layers), id(self.lang_coeff))
+            lw = self._dev_cache.get(key)
+            if lw is None:
+                lc = torch.as_tensor(self.lang_coeff, dtype=torch.float32).reshape(-1).to(device)
+                lw = lc.expand(nl) if lc.shape[0] == 1 else lc[torch.as_tensor(list(layers), device=device)]
+                self._dev_cache[key] = lw = lw.contiguous()
         else:
             raise NotImplementedError
         return lw, 1.0 - lw

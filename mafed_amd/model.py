@@ -174,6 +174,9 @@ class VLPythiaForCausalLM(nn.Module):
         # callable(i): fired when layer i's parameter gradients are final for this backward; i = L for the LM head /
         # final LayerNorm, -1 when everything (embeddings, projector) is done.  Used by the DDP bucket reducer.
         self.grad_ready_hook = None
+        self._side = None
+        self._view_cache: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.overlap_param_grads = True  # run dW / bias-gradient kernels on side_stream() concurrently with the dX chain
         self.reset_parameters(seed)
         self.register_load_state_dict_post_hook(lambda m, ik: setattr(m, "_shadow_dirty", True))
 
@@ -276,12 +279,22 @@ class VLPythiaForCausalLM(nn.Module):
                 p.data = self.flat_params[o:o + n].view(shape)
                 p.grad = self.flat_grads[o:o + n].view(shape)
             self._rot_cache.clear()
+            self._view_cache.clear()
+            self._side = None
             self._shadow_dirty = True
             enc = getattr(self.vision_encoder, "encoder", None)
             if enc is not None:
                 enc._apply(fn)
             return self
         return self
+
+    # ---- streams ---------------------------------------------------------------------------------------------------
+    def side_stream(self):
+        """Second HIP stream of this replica: parameter-gradient GEMMs (dW = dY^T.X, bias column sums) run here, off the
+        critical dX chain, so their small grids (64-256 tiles at 410M) share the chip with the main stream's kernels."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat_params.device)
+        return self._side
 
     # ---- parameter views ---------------------------------------------------------------------------------------
     def sync_shadow(self):
@@ -290,19 +303,25 @@ class VLPythiaForCausalLM(nn.Module):
             ops.cast(self.flat_params, torch.bfloat16, out=self.flat_shadow)
         self._shadow_dirty = False
 
+    def _view(self, cache_id: int, src: torch.Tensor, name: str) -> torch.Tensor:
+        """Cached view of one tensor inside a flat buffer (the host path looks these up ~40 times per layer per step)."""
+        key = (cache_id, name)
+        v = self._view_cache.get(key)
+        if v is None or v._base is not src:
+            o, n, shape = self._offsets[name]
+            v = src[o:o + n].view(shape)
+            self._view_cache[key] = v
+        return v
+
     def _w(self, name: str) -> torch.Tensor:
         """Weight in compute dtype."""
-        o, n, shape = self._offsets[name]
-        src = self.flat_shadow if self.compute_dtype == torch.bfloat16 else self.flat_params
-        return src[o:o + n].view(shape)
+        return self._view(0, self.flat_shadow if self.compute_dtype == torch.bfloat16 else self.flat_params, name)
 
     def _p(self, name: str) -> torch.Tensor:
-        o, n, shape = self._offsets[name]
-        return self.flat_params[o:o + n].view(shape)
+        return self._view(1, self.flat_params, name)
 
     def _g(self, name: str) -> torch.Tensor:
-        o, n, shape = self._offsets[name]
-        return self.flat_grads[o:o + n].view(shape)
+        return self._view(2, self.flat_grads, name)
 
     def zero_grad(self, set_to_none: bool = False):  # gradients are views of the flat buffer: always zero in place
         self.flat_grads.zero_()
@@ -474,20 +493,45 @@ class VLPythiaForCausalLM(nn.Module):
         dev = self.flat_params.device
         if len(dhidden) > L and dhidden[L] is not None:
             raise NotImplementedError("gradient w.r.t. the post-final-LayerNorm hidden state is not on the MAFED path")
+        main = torch.cuda.current_stream()
+        side = self.side_stream() if self.overlap_param_grads else None
+        keep: List[torch.Tensor] = []  # temporaries read by the side stream: kept alive until the join at the end
+
+        def on_side(fn, *tensors):
+            """Run parameter-gradient work after everything queued on the main stream so far, off the dX chain."""
+            if side is None:
+                fn()
+                return
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+            keep.extend(tensors)
+
+        def wgrad(dY, X, wname, bname=None):
+            def run():
+                ops.gemm(dY, X, True, False, out=g(wname), beta=1.0)
+                if bname is not None:
+                    ops.colsum_(dY, g(bname))
+            on_side(run, dY, X)
+
+        def ready(i):
+            if self.grad_ready_hook is not None:
+                on_side(lambda: self.grad_ready_hook(i))
+
         dx = None  # gradient w.r.t. the residual stream leaving the current layer, fp32 [rows, h]
         if dloss is not None and sv["loss"] is not None:
             xt, lnf, fmean, frstd = sv["final"]
             logits = sv["logits"]
             gl = dloss.reshape(1).to(torch.float32).contiguous()
             dlog = ops.ce_bwd(logits, sv["labels"], sv["ce_lse"], gl).view(B * T, cfg.vocab_size)
-            ops.gemm(dlog, lnf, True, False, out=g("embed_out.weight"), beta=1.0)
+            wgrad(dlog, lnf, "embed_out.weight")
             dlnf = ops.gemm(dlog, w("embed_out.weight"), False, False)
             dxt, _ = ops.layernorm_bwd(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None,
                                        g("gpt_neox.final_layer_norm.weight"), g("gpt_neox.final_layer_norm.bias"))
             dx = torch.zeros((rows, h), dtype=torch.float32, device=dev)
             dx.view(B, S, h)[:, P:, :] = dxt.view(B, T, h)
-            if self.grad_ready_hook is not None:
-                self.grad_ready_hook(L)
+            ready(L)
         dy = None  # dx in compute dtype (GEMM operand)
         for i in range(L - 1, -1, -1):
             ext = dhidden[i + 1] if (i + 1) < min(len(dhidden), L) else None  # grad of hidden_states[i+1] = output of layer i
@@ -501,20 +545,17 @@ class VLPythiaForCausalLM(nn.Module):
                 dy = dx if cd == torch.float32 else ops.cast(dx, cd)
             pre = f"gpt_neox.layers.{i}."
             s = sv["layers"][i]
+            # parameter gradients that only need dy: MLP down-projection and attention output projection
+            wgrad(dy, s["a"], pre + "mlp.dense_4h_to_h.weight", pre + "mlp.dense_4h_to_h.bias")
+            wgrad(dy, s["ao"], pre + "attention.dense.weight", pre + "attention.dense.bias")
             # MLP branch
-            ops.gemm(dy, s["a"], True, False, out=g(pre + "mlp.dense_4h_to_h.weight"), beta=1.0)
-            ops.colsum_(dy, g(pre + "mlp.dense_4h_to_h.bias"))
             du = ops.gemm(dy, w(pre + "mlp.dense_4h_to_h.weight"), False, False, epilogue=EPI_GELU_BWD, aux=s["u"])
-            ops.gemm(du, s["ln2"], True, False, out=g(pre + "mlp.dense_h_to_4h.weight"), beta=1.0)
-            ops.colsum_(du, g(pre + "mlp.dense_h_to_4h.bias"))
+            wgrad(du, s["ln2"], pre + "mlp.dense_h_to_4h.weight", pre + "mlp.dense_h_to_4h.bias")
             dln2 = ops.gemm(du, w(pre + "mlp.dense_h_to_4h.weight"), False, False)
             # attention branch
-            ops.gemm(dy, s["ao"], True, False, out=g(pre + "attention.dense.weight"), beta=1.0)
-            ops.colsum_(dy, g(pre + "attention.dense.bias"))
             dao = ops.gemm(dy, w(pre + "attention.dense.weight"), False, False)
             dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, S, H, D, rot, cos, sin, am)
-            ops.gemm(dqkv, s["ln1"], True, False, out=g(pre + "attention.query_key_value.weight"), beta=1.0)
-            ops.colsum_(dqkv, g(pre + "attention.query_key_value.bias"))
+            wgrad(dqkv, s["ln1"], pre + "attention.query_key_value.weight", pre + "attention.query_key_value.bias")
             dln1 = ops.gemm(dqkv, w(pre + "attention.query_key_value.weight"), False, False)
             # both LayerNorms + the residual path, one pass; also emits the compute-dtype copy the next layer's GEMMs read
             dx, dy = ops.layernorm_bwd(dln1, dln2, s["x"], s["mean"], s["rstd"], self._p(pre + "input_layernorm.weight"),
@@ -526,8 +567,7 @@ class VLPythiaForCausalLM(nn.Module):
                 dy = dx
             if taps is not None and i in taps:
                 taps[i] = dx  # = dL/d hidden_states[i] (fresh buffer, never written again on this path)
-            if self.grad_ready_hook is not None:
-                self.grad_ready_hook(i)
+            ready(i)
         ext0 = dhidden[0] if len(dhidden) > 0 else None
         if ext0 is not None:
             ext0 = ext0.reshape(rows, h)
@@ -535,13 +575,13 @@ class VLPythiaForCausalLM(nn.Module):
         if dx is not None:
             fc, u0, a0 = sv["proj"]
             dimg = ops.embed_concat_bwd(dx, sv["input_ids"], B, P, T, h, cfg.vocab_size, g("gpt_neox.embed_in.weight"), cd)
-            ops.gemm(dimg, a0, True, False, out=g("vision_embed_tokens.2.weight"), beta=1.0)
-            ops.colsum_(dimg, g("vision_embed_tokens.2.bias"))
+            wgrad(dimg, a0, "vision_embed_tokens.2.weight", "vision_embed_tokens.2.bias")
             du0 = ops.gemm(dimg, w("vision_embed_tokens.2.weight"), False, False, epilogue=EPI_GELU_BWD, aux=u0)
-            ops.gemm(du0, fc, True, False, out=g("vision_embed_tokens.0.weight"), beta=1.0)
-            ops.colsum_(du0, g("vision_embed_tokens.0.bias"))
-        if self.grad_ready_hook is not None:
-            self.grad_ready_hook(-1)
+            wgrad(du0, fc, "vision_embed_tokens.0.weight", "vision_embed_tokens.0.bias")
+        ready(-1)
+        if side is not None:
+            main.wait_stream(side)  # gradients complete (and `keep` safe to release) from the main stream's point of view
+        keep.clear()
 
 
 class _ModelFn(torch.autograd.Function):

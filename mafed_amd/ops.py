@@ -33,6 +33,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Fn:
+    """Lazily bound entry points (one attribute lookup per call instead of load() + getattr)."""
+
+    def __getattr__(self, name):
+        fn = getattr(_lib.load(), "mafed_" + name)
+        setattr(self, name, fn)
+        return fn
+
+
+_fn = _Fn()
+
+
 class Workspace:
     """Grow-only scratch buffer handed to kernels that need one (no allocation inside the library)."""
 
@@ -76,14 +88,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
     assert out.shape == (M, N) and out.stride(1) == 1
-    lib = _lib.load()
     prof = GEMM_EVENTS is not None and A.dtype == torch.bfloat16
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.mafed_gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
-                         out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream()),
-          "mafed_gemm")
+    rc = _fn.gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
+                  out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream())
+    if rc:
+        check(rc, "mafed_gemm")
     if prof:
         e1.record()
         GEMM_EVENTS.append((e0, e1, 2.0 * M * N * K))
@@ -93,11 +105,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
 def colsum_(X: torch.Tensor, out: torch.Tensor) -> None:
     """out[n] += sum_m X[m, n]"""
     assert X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32
-    lib = _lib.load()
     M, N = X.shape
-    nb = lib.mafed_colsum_workspace_bytes(M, N)
-    ws = workspace(X.device).get(nb)
-    check(lib.mafed_colsum(_ptr(X), _dt(X), M, N, X.stride(0), _ptr(out), _ptr(ws), ws.numel(), _stream()), "mafed_colsum")
+    check(_lib.load().mafed_colsum(_ptr(X), _dt(X), M, N, X.stride(0), _ptr(out), 0, 0, _stream()), "mafed_colsum")
 
 
 def layernorm_fwd(x: torch.Tensor, w1, b1, w2=None, b2=None, eps: float = 1e-5, out_dtype=torch.float32, save_stats: bool = True):
@@ -246,6 +255,11 @@ def gradnorm_clip(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor]
 def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None) -> None:
     check(_lib.load().mafed_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
                                        int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
+
+
+def optim_advance_(state: torch.Tensor, base_lr: float, warmup: int, total: int, beta1: float, beta2: float, hyper: torch.Tensor) -> None:
+    check(_lib.load().mafed_optim_advance(_ptr(state), float(base_lr), int(warmup), int(total), float(beta1), float(beta2),
+                                          _ptr(hyper), _stream()), "mafed_optim_advance")
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

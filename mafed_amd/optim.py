@@ -53,7 +53,11 @@ class FlatAdamW:
         dev = model.flat_params.device
         self.exp_avg = torch.zeros_like(model.flat_params)
         self.exp_avg_sq = torch.zeros_like(model.flat_params)
-        self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
+        # {lr, 1-b1^t, sqrt(1-b2^t)} of the current step and the step counter live on the DEVICE (mafed_optim_advance):
+        # the optimiser kernels carry no per-step host constants, so a whole step replays from a hipGraph
+        self.lr_dev = torch.tensor([lr, 1.0, 1.0], dtype=torch.float32, device=dev)
+        self.state_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._sched = (0, 0)  # (warmup_steps, total_steps); total 0 = constant lr
         self.clip_out = torch.ones(2, dtype=torch.float32, device=dev)  # {grad norm, clip scale}
         self.step_count = 0
         n_decay = model.decay_split()
@@ -63,7 +67,18 @@ class FlatAdamW:
     def set_lr(self, lr: float) -> None:
         for g in self.param_groups:
             g["lr"] = lr
-        self.lr_dev.fill_(lr)
+
+    def attach_schedule(self, warmup_steps: int, total_steps: int) -> None:
+        """Linear warm-up / decay evaluated on the device each step (get_linear_schedule_with_warmup semantics)."""
+        self._sched = (int(warmup_steps), int(total_steps))
+
+    def advance(self) -> None:
+        """First kernel of an optimiser step (capturable): t += 1 and {lr(t-1), 1-b1^t, sqrt(1-b2^t)} -> lr_dev."""
+        ops.optim_advance_(self.state_dev, self.base_lr, self._sched[0], self._sched[1], self.betas[0], self.betas[1], self.lr_dev)
+
+    def host_advance(self) -> None:
+        """Host mirror of the step counter (logging, state_dict); no device work."""
+        self.step_count += 1
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.model.flat_grads.zero_()
@@ -75,8 +90,13 @@ class FlatAdamW:
         return self.clip_out[0]
 
     def step(self, grad_mul: float = 1.0) -> None:
+        self.host_advance()
+        self.advance()
+        self.apply(grad_mul)
+
+    def apply(self, grad_mul: float = 1.0) -> None:
+        """Device half of a step (capturable): the AdamW kernels, reading this step's scalars from device memory."""
         m = self.model
-        self.step_count += 1
         clip = self.clip_out if getattr(self, "_clip_pending", False) else None
         for grp in self.param_groups:
             lo, hi = grp["range"]
@@ -84,19 +104,20 @@ class FlatAdamW:
                 continue
             shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
             ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
-                            self.betas[0], self.betas[1], self.eps, grp["weight_decay"], self.step_count, clip, grad_mul, shadow)
+                            self.betas[0], self.betas[1], self.eps, grp["weight_decay"], 0, clip, grad_mul, shadow)
         self._clip_pending = False
         if m.flat_shadow is not None:
             m._shadow_dirty = False
 
     def state_dict(self):
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "sched": self._sched}
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
-        self.set_lr(float(sd["lr"]))
+        self.state_dev.fill_(self.step_count)
+        self._sched = tuple(sd.get("sched", self._sched))
 
 
 class LinearWarmupSchedule:
@@ -106,12 +127,14 @@ class LinearWarmupSchedule:
     def __init__(self, optimizer: FlatAdamW, warmup_steps: int, total_steps: int, last_epoch: int = -1):
         self.optimizer, self.warmup_steps, self.total_steps = optimizer, warmup_steps, total_steps
         self.last_epoch = last_epoch
+        optimizer.attach_schedule(warmup_steps, total_steps)  # the device evaluates the same lambda from its own step counter
         self.step()
 
     def get_last_lr(self):
         return [g["lr"] for g in self.optimizer.param_groups]
 
     def step(self) -> None:
+        """Host mirror (param_groups[...]["lr"], get_last_lr); the kernels read the device-side value."""
         self.last_epoch += 1
         self.optimizer.set_lr(self.optimizer.base_lr * lr_lambda(self.last_epoch, self.warmup_steps, self.total_steps))
 

@@ -20,9 +20,49 @@ from mafed_amd.dist import GradReducer
 from mafed_amd.optim import FlatAdamW, compute_warmup, get_linear_schedule_with_warmup
 
 
+class _StaticLoader:
+    """``next(iter(loader))`` yields (a shallow copy of) one static batch dict: the buffers a captured graph reads."""
+
+    def __init__(self, static_batch: Dict[str, torch.Tensor]):
+        self.static = static_batch
+
+    def __iter__(self):
+        while True:
+            yield dict(self.static)
+
+
+class _GraphedStep:
+    """One variant (replay / task branch x with / without optimiser step) of the device part of a step, captured into a
+    hipGraph: forward, loss, hand-scheduled backward on two streams, clip, AdamW, gradient zeroing.  Replaying it costs
+    one launch; the ~1700 kernel launches of an eager step cost more host time than the GPU needs to run them."""
+
+    def __init__(self, trainer: "Trainer", is_replay: bool, window_end: bool, task_batch, mem_batch):
+        self.static_task = {k: v.clone() for k, v in task_batch.items() if isinstance(v, torch.Tensor)}
+        self.static_mem = {k: v.clone() for k, v in mem_batch.items() if isinstance(v, torch.Tensor)} if mem_batch is not None else None
+        self.graph = torch.cuda.CUDAGraph()
+        real_loader = trainer.cl_method.mem_dataloader if is_replay else None
+        if is_replay:
+            trainer.cl_method.mem_dataloader = _StaticLoader(self.static_mem)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.rec = trainer._device_step(self.static_task, is_replay, window_end)
+        finally:
+            if is_replay:
+                trainer.cl_method.mem_dataloader = real_loader
+
+    def replay(self, task_batch, mem_batch):
+        for k, v in self.static_task.items():
+            v.copy_(task_batch[k], non_blocking=True)
+        if self.static_mem is not None:
+            for k, v in self.static_mem.items():
+                v.copy_(mem_batch[k], non_blocking=True)
+        self.graph.replay()
+        return self.rec
+
+
 class Trainer:
     def __init__(self, model, cl_method, config: Optional[Any] = None, task_id: int = 0, n_batches_per_epoch: int = 1000,
-                 process_group=None, ddp: bool = False, bucket_mb: float = 64.0):
+                 process_group=None, ddp: bool = False, bucket_mb: float = 64.0, use_graphs: bool = False):
         cfg = config if config is not None else SimpleNamespace()
         self.config = cfg
         self.model = model
@@ -41,6 +81,11 @@ class Trainer:
         total = int(getattr(cfg, "total_steps", total))
         self.scheduler = get_linear_schedule_with_warmup(self.optimizer, warm, total, last_epoch=-1)
         self.reducer = GradReducer(model, process_group, bucket_mb) if ddp else None
+        # hipGraph replay of the device part of a step.  Needs fixed batch shapes and CL hooks that do no per-step host work
+        # (true for Naive / ER / FeatureDistillation, whose update_after_* are no-ops on this path).
+        self.use_graphs = bool(use_graphs) and self.reducer is None
+        self._graphs: Dict[Any, _GraphedStep] = {}
+        self._eager_seen: Dict[Any, int] = {}
         self.global_step = 0
         self.optimizer.zero_grad()
         self.on_train_start()
@@ -49,12 +94,18 @@ class Trainer:
     def on_train_start(self):
         self.cl_method.num_training_steps = getattr(self.scheduler, "total_steps", None)
 
+    def _is_replay_step(self, batch_idx: int) -> bool:
+        return self.task_id > 0 and (batch_idx + 1) % self.replay_interval == 0
+
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int):
         """Replay / MAFED step iff task_id > 0 and (batch_idx+1) % replay_interval == 0 -- the current-task batch is
         then dropped; otherwise plain CE through cl_method.compute_loss."""
+        return self._training_step(batch, self._is_replay_step(batch_idx))
+
+    def _training_step(self, batch, is_replay: bool):
         loss = None
         branch = "task"
-        if self.task_id > 0 and (batch_idx + 1) % self.replay_interval == 0:
+        if is_replay:
             loss, _ = self.cl_method.replay(self.model)
             if loss is not None:
                 branch = "replay"
@@ -63,24 +114,45 @@ class Trainer:
             loss = self.cl_method.compute_loss(self.model, loss, batch=batch)
         return loss, branch
 
-    def step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, Any]:
-        window_end = (batch_idx + 1) % self.accumulate == 0
+    def _device_step(self, batch, is_replay: bool, window_end: bool) -> Dict[str, Any]:
+        """Everything of a step that runs on the GPU, in Lightning's order (capturable: no host synchronisation)."""
         if self.reducer is not None:
             self.reducer.enabled = window_end  # all-reduce only on the last micro-batch of an accumulation window
-        loss, branch = self.training_step(batch, batch_idx)
+        loss, branch = self._training_step(batch, is_replay)
         (loss / self.accumulate if self.accumulate != 1 else loss).backward()
         rec: Dict[str, Any] = {"loss": loss.detach(), "branch": branch, "stepped": False}
         if window_end:
             self.cl_method.update_after_backward(model=self.model)  # on_before_optimizer_step
             if self.reducer is not None:
                 self.reducer.wait()
-            rec["lr"] = self.optimizer.param_groups[0]["lr"]
             if self.grad_norm and self.grad_norm > 0:
                 rec["grad_norm"] = self.optimizer.clip_grad_norm_(self.grad_norm).clone()
-            self.optimizer.step()
-            self.scheduler.step()
+            self.optimizer.advance()
+            self.optimizer.apply()
             self.optimizer.zero_grad()
-            self.global_step += 1
             rec["stepped"] = True
+        return rec
+
+    def step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, Any]:
+        window_end = (batch_idx + 1) % self.accumulate == 0
+        is_replay = self._is_replay_step(batch_idx) and getattr(self.cl_method, "mem_dataloader", True) is not None
+        key = (is_replay, window_end)
+        lr_now = self.optimizer.param_groups[0]["lr"]
+        if self.use_graphs and (key in self._graphs or self._eager_seen.get(key, 0) >= 2):
+            mem = next(iter(self.cl_method.mem_dataloader)) if is_replay else None
+            gs = self._graphs.get(key)
+            if gs is None:
+                torch.cuda.synchronize()
+                gs = self._graphs[key] = _GraphedStep(self, is_replay, window_end, batch, mem)
+                rec = dict(gs.rec)  # the capture pass itself does not execute: replay it once for this step
+            rec = dict(gs.replay(batch, mem))
+        else:
+            rec = self._device_step(batch, is_replay, window_end)
+            self._eager_seen[key] = self._eager_seen.get(key, 0) + 1
+        if window_end:
+            rec["lr"] = lr_now
+            self.optimizer.host_advance()
+            self.scheduler.step()
+            self.global_step += 1
         self.cl_method.update_after_step(model=self.model, batch_idx=batch_idx)  # on_train_batch_end
         return rec
