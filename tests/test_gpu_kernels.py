@@ -56,9 +56,9 @@ def _int_mat(shape, g, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320)])
 def test_gemm_bf16_exact_integers(tA, tB, M, N, K, variant):
     """Small-integer operands are exact in bf16 and the fp32 accumulator: any wrong fragment / transposing-read /
     swizzle mapping shows up as a hard mismatch (asymmetric data)."""
@@ -72,7 +72,8 @@ def test_gemm_bf16_exact_integers(tA, tB, M, N, K, variant):
     A = _int_mat((K, M) if tA else (M, K), g)
     B = _int_mat((N, K) if tB else (K, N), g)
     from mafed_amd import _lib
-    _lib.load().mafed_gemm_set_variant(variant)  # 0: LDS-DMA kernel on tile-aligned shapes, 1: register-staged kernel everywhere
+    # 0: automatic; 1: register-staged kernel everywhere; 10+c: LDS-DMA tile configuration c where the shape allows it
+    _lib.load().mafed_gemm_set_variant(variant)
     try:
         C = ops.gemm(A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16), tA, tB, out_dtype=torch.float32)
     finally:
