@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of hipGraph replay of the step")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
     args = ap.parse_args()
 
     from mafed_amd import FeatureDistillation, Trainer, VLPythiaConfig, VLPythiaForCausalLM, ops
@@ -121,6 +122,9 @@ def main():
     broadcast_teacher(fd.past_model)
     fd.task_id = 1
     fd.num_vision_tokens = P
+    if args.no_overlap:
+        student.overlap_param_grads = False
+        fd.overlap_teacher = False
     n_mem = 8 * B
     gcpu = torch.Generator().manual_seed(1235 + rank)
     ids = torch.randint(1, cfg.vocab_size, (n_mem, T), generator=gcpu)

@@ -177,6 +177,9 @@ int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* strea
 /* test / tuning hook: 0 = automatic kernel choice, 1 = force the register-staged MFMA GEMM (the ragged-shape kernel) */
 int mafed_gemm_set_variant(int variant);
 
+/* test / tuning hook: 0 = automatic (one-block-per-head "resident" kernels when K/V fit in LDS), 1 = tiled kernels only */
+int mafed_attn_set_variant(int variant);
+
 /* test hook: the exact (non-MFMA) forward kernel on bf16 data -- on-GPU cross-check of the MFMA kernels */
 int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                               const int64_t* attention_mask, int T, void* out, float* lse, void* stream);

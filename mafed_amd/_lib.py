@@ -29,6 +29,7 @@ SIGNATURES = {
     "mafed_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _z, _p]),
     "mafed_attn_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_attn_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "mafed_attn_set_variant": (_i, [_i]),
     "mafed_attn_fwd_exact_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_embed_concat_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _l, _p, _p]),
     "mafed_embed_concat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _l, _p, _i, _p, _p]),

@@ -20,4 +20,6 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
 int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
                          const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st);
 
+void attn_mfma_set_variant(int v);  // 0 automatic (resident kernels when K/V fit in LDS), 1 tiled kernels only
+
 }  // namespace mafed

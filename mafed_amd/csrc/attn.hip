@@ -60,6 +60,12 @@ extern "C" int mafed_attn_bwd(const void* qkv, const void* out, const void* dout
   return MAFED_OK;
 }
 
+// test / tuning hook: 0 = automatic, 1 = tiled MFMA kernels even when the resident ones fit
+extern "C" int mafed_attn_set_variant(int variant) {
+  attn_mfma_set_variant(variant);
+  return MAFED_OK;
+}
+
 // test hook: run the exact kernels on bf16 data (on-GPU cross-check of the MFMA kernels)
 extern "C" int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                                          const int64_t* attention_mask, int T, void* out, float* lse, void* stream) {

@@ -118,6 +118,50 @@ __device__ __forceinline__ void load_col_frags(bf16x8 (&f)[D / 32], const bf16_t
   }
 }
 
+// Two-phase form of load_col_frags for software pipelining across slices: issue the raw 16-byte loads (and the rotary
+// partner chunk + cos/sin rows where needed) for the NEXT slice before computing the current one; finish (rotate, cast)
+// when the slice starts, a whole slice of MFMAs later.
+template <int D>
+struct ColRaw {
+  uint4 x[D / 32];
+  uint4 y;
+  float4 c0, c1, s0, s1;
+};
+template <int D, bool ROT>
+__device__ __forceinline__ void col_raw_issue(ColRaw<D>& r, const bf16_t* __restrict__ base, int64_t rstride, int row0, int S, int rot,
+                                              const float* __restrict__ rc, const float* __restrict__ rs, int lane) {
+  const int row = row0 + (lane & 15), g = lane >> 4;
+  const bool valid = row < S;
+  const bf16_t* rowp = base + (int64_t)row * rstride;
+#pragma unroll
+  for (int ks = 0; ks < D / 32; ++ks) r.x[ks] = valid ? *reinterpret_cast<const uint4*>(rowp + (ks * 4 + g) * 8) : make_uint4(0u, 0u, 0u, 0u);
+  if (ROT && g * 8 < rot && valid) {
+    const int hc = rot >> 4;
+    r.y = *reinterpret_cast<const uint4*>(rowp + (g ^ hc) * 8);
+    const int d0 = (g < hc ? g : g - hc) * 8;
+    const float* c = rc + (int64_t)row * (rot >> 1) + d0;
+    const float* sn = rs + (int64_t)row * (rot >> 1) + d0;
+    r.c0 = load4(c); r.c1 = load4(c + 4); r.s0 = load4(sn); r.s1 = load4(sn + 4);
+  }
+}
+template <int D, bool ROT>
+__device__ __forceinline__ void col_raw_finish(bf16x8 (&f)[D / 32], const ColRaw<D>& r, int row0, int S, int rot, int lane) {
+  const int row = row0 + (lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < D / 32; ++ks) f[ks] = __builtin_bit_cast(bf16x8, r.x[ks]);
+  if (ROT && g * 8 < rot && row < S) {
+    const bool first = g < (rot >> 4);
+    float xf[8], yf[8], o[8];
+    unpack8(r.x[0], xf);
+    unpack8(r.y, yf);
+    const float c[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+    const float sn[8] = {r.s0.x, r.s0.y, r.s0.z, r.s0.w, r.s1.x, r.s1.y, r.s1.z, r.s1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = first ? (xf[e] * c[e] - yf[e] * sn[e]) : (xf[e] * c[e] + yf[e] * sn[e]);
+    f[0] = __builtin_bit_cast(bf16x8, pack8(o));
+  }
+}
+
 // reduce over the four lanes that share lane&15 (the 4 row groups of an accumulator column)
 __device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
@@ -439,8 +483,357 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// "Resident" kernels for short sequences (S = 288 on the MAFED path): ONE block per (batch, head) stages the whole K and
+// V (or Q and dO for dK/dV) of that head into LDS once -- 288 x 64 x 2 B x 2 = 72 KiB at D = 64, two blocks per CU --
+// and its four waves walk the 16-row slices in a zig-zag order that balances the causal work.  No per-tile re-staging
+// (the tiled kernels above re-read K/V 3.2x at S = 288 and pay two barriers per 64 keys), no barrier after the first.
+// The tiled kernels remain the path for sequences whose K/V do not fit.
+// ------------------------------------------------------------------------------------------------------------
+template <int D, bool ROT>
+__device__ __forceinline__ void stage_all_rows(char* __restrict__ img, const bf16_t* __restrict__ base, int64_t rstride, int nrows_pad, int S,
+                                               int rot, const float* __restrict__ rc, const float* __restrict__ rs, int tid) {
+  // batches of U chunks per thread: all global loads of a batch are issued before the first LDS write, so the HBM/L2
+  // latency is paid once per batch instead of once per 16 bytes (a runtime-bounded loop is not pipelined by hipcc)
+  constexpr int CPR = D / 8, U = 6;
+  const int total = nrows_pad * CPR;
+  for (int c0 = tid; c0 < total; c0 += 256 * U) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 256 * u;
+      const int row = c / CPR, ch = c % CPR;
+      if (c < total) {
+        if (ROT) v[u] = load_chunk_rot(base + (int64_t)row * rstride, ch, rot, rc, rs, row, row < S);
+        else v[u] = row < S ? *reinterpret_cast<const uint4*>(base + (int64_t)row * rstride + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 256 * u;
+      if (c < total) *reinterpret_cast<uint4*>(img + tile_off<D>(c / CPR, c % CPR)) = v[u];
+    }
+  }
+}
+
+// slice order of wave w: w, 7-w, 8+w, 15-w, 16+w, ...  (16-row slices; causal cost grows with the slice index)
+__device__ __forceinline__ int zigzag_slice(int w, int t) { return (t >> 1) * 8 + ((t & 1) ? 7 - w : w); }
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
+                                                           const float* __restrict__ rs, const int64_t* __restrict__ am,
+                                                           bf16_t* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int spad = (S + 63) / 64 * 64;
+  char* kimg = lds;
+  char* vimg = lds + spad * D * 2;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const bf16_t* kb = qb + D;
+  const bf16_t* vb = qb + 2 * D;
+  stage_all_rows<D, true>(kimg, kb, rstride, spad, S, rot, rc, rs, tid);
+  stage_all_rows<D, false>(vimg, vb, rstride, spad, S, rot, rc, rs, tid);
+  __syncthreads();
+  const int g = lane >> 4;
+  const float scale = rsqrtf((float)D);
+  const int nslices = (S + 15) / 16;
+  ColRaw<D> qraw;
+  col_raw_issue<D, true>(qraw, qb, rstride, zigzag_slice(wave, 0) * 16, S, rot, rc, rs, lane);  // slice 0..3 always exists... or is all-zero
+  for (int t = 0;; ++t) {
+    const int slice = zigzag_slice(wave, t);
+    if (slice >= nslices) break;  // zig-zag order is increasing per wave except inside a pair; a pair's later member is checked below
+    const int q0 = slice * 16;
+    const int myq = q0 + (lane & 15);
+    bf16x8 qf[D / 32];
+    col_raw_finish<D, true>(qf, qraw, q0, S, rot, lane);
+    {
+      const int nxt = zigzag_slice(wave, t + 1);
+      if (nxt < nslices) col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
+    }
+    f32x4 o[D / 16];
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const int last_kt = (q0 + 15) / 64;
+    for (int kt = 0; kt <= last_kt; ++kt) {
+      f32x4 s[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks)
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s[j], 0, 0, 0);
+      }
+      const bool need_mask = (kt == last_kt) || (kt * 64 + 63 >= P);
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[j][r] * scale;
+          if (need_mask) {
+            const int key = kt * 64 + j * 16 + 4 * g + r;
+            if (key > myq || !key_ok(am, b, key, P, T, S)) v = -INFINITY;
+          }
+          s[j][r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      tmax = col_max(tmax);
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __expf(m - mn);
+      m = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(s[j][r] - mn);
+          s[j][r] = pv;
+          ps += pv;
+        }
+      l = l * alpha + ps;
+#pragma unroll
+      for (int i = 0; i < D / 16; ++i) o[i] *= alpha;
+      const bf16x8 p0 = pack_acc(s[0], s[1]), p1 = pack_acc(s[2], s[3]);
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2, lane), p0, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2 + 1, lane), p1, o[dt], 0, 0, 0);
+      }
+    }
+    l = col_sum(l);
+    if (myq < S) {
+      const float inv = 1.0f / l;
+      bf16_t* op = out + ((int64_t)b * S + myq) * H * D + (int64_t)h * D;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt)
+        store4(op + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
+      if (g == 0) lse[((int64_t)b * H + h) * S + myq] = m + logf(l);
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse, AttnShape sh,
+                                                              const float* __restrict__ rc, const float* __restrict__ rs,
+                                                              const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
+                                                              float* __restrict__ delta) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int spad = (S + 63) / 64 * 64;
+  char* kimg = lds;
+  char* vimg = lds + spad * D * 2;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const bf16_t* kb = qb + D;
+  const bf16_t* vb = qb + 2 * D;
+  const int64_t ostride = (int64_t)H * D;
+  const bf16_t* ob = out + (int64_t)b * S * ostride + (int64_t)h * D;
+  const bf16_t* dob = dout + (int64_t)b * S * ostride + (int64_t)h * D;
+  stage_all_rows<D, true>(kimg, kb, rstride, spad, S, rot, rc, rs, tid);
+  stage_all_rows<D, false>(vimg, vb, rstride, spad, S, rot, rc, rs, tid);
+  __syncthreads();
+  const int g = lane >> 4;
+  const float scale = rsqrtf((float)D);
+  const int nslices = (S + 15) / 16;
+  ColRaw<D> qraw, doraw, oraw;
+  {
+    const int s0 = zigzag_slice(wave, 0) * 16;
+    col_raw_issue<D, true>(qraw, qb, rstride, s0, S, rot, rc, rs, lane);
+    col_raw_issue<D, false>(doraw, dob, ostride, s0, S, 0, rc, rs, lane);
+    col_raw_issue<D, false>(oraw, ob, ostride, s0, S, 0, rc, rs, lane);
+  }
+  for (int t = 0;; ++t) {
+    const int slice = zigzag_slice(wave, t);
+    if (slice >= nslices) break;
+    const int q0 = slice * 16;
+    const int myq = q0 + (lane & 15);
+    bf16x8 qf[D / 32], dof[D / 32];
+    col_raw_finish<D, true>(qf, qraw, q0, S, rot, lane);
+    col_raw_finish<D, false>(dof, doraw, q0, S, 0, lane);
+    float dl = 0.f;
+    {
+      bf16x8 of[D / 32];
+      col_raw_finish<D, false>(of, oraw, q0, S, 0, lane);
+      const int nxt = zigzag_slice(wave, t + 1);
+      if (nxt < nslices) {
+        col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
+        col_raw_issue<D, false>(doraw, dob, ostride, nxt * 16, S, 0, rc, rs, lane);
+        col_raw_issue<D, false>(oraw, ob, ostride, nxt * 16, S, 0, rc, rs, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < D / 32; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[ks][e];
+      dl = col_sum(dl);
+    }
+    float L = 0.f;
+    if (myq < S) {
+      L = lse[((int64_t)b * H + h) * S + myq];
+      if (g == 0) delta[((int64_t)b * H + h) * S + myq] = dl;
+    }
+    f32x4 dq[D / 16];
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int last_kt = (q0 + 15) / 64;
+    for (int kt = 0; kt <= last_kt; ++kt) {
+      const bool need_mask = (kt == last_kt) || (kt * 64 + 63 >= P);
+      f32x4 ds[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(vimg, kt * 4 + j, ks, lane), dof[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = __expf(s[r] * scale - L);
+          if (need_mask) {
+            const int key = kt * 64 + j * 16 + 4 * g + r;
+            if (key > myq || !key_ok(am, b, key, P, T, S)) pv = 0.f;
+          }
+          ds[j][r] = pv * (dp[r] - dl) * scale;
+        }
+      }
+      const bf16x8 d0 = pack_acc(ds[0], ds[1]), d1 = pack_acc(ds[2], ds[3]);
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2, lane), d0, dq[dt], 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2 + 1, lane), d1, dq[dt], 0, 0, 0);
+      }
+    }
+    bf16_t* dqp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)myq * rstride;
+    store_grad_unrot<D>(dqp, dq, rot, rc, rs, myq, lane, myq < S);
+  }
+}
+
+// dK / dV: Q (rotated) and dO of the head are resident; each wave owns 16-key slices, heaviest (lowest keys) first
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta, AttnShape sh,
+                                                               const float* __restrict__ rc, const float* __restrict__ rs,
+                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int spad = (S + 63) / 64 * 64;
+  char* qimg = lds;
+  char* doimg = lds + spad * D * 2;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
+  const bf16_t* kb = qb + D;
+  const bf16_t* vb = qb + 2 * D;
+  const int64_t ostride = (int64_t)H * D;
+  const bf16_t* dob = dout + (int64_t)b * S * ostride + (int64_t)h * D;
+  stage_all_rows<D, true>(qimg, qb, rstride, spad, S, rot, rc, rs, tid);
+  stage_all_rows<D, false>(doimg, dob, ostride, spad, S, 0, rc, rs, tid);
+  __syncthreads();
+  const int g = lane >> 4;
+  const float scale = rsqrtf((float)D);
+  const int nslices = (S + 15) / 16;
+  const int nqt = spad / 64;
+  const float* Lrow = lse + ((int64_t)b * H + h) * S;
+  const float* Drow = delta + ((int64_t)b * H + h) * S;
+  ColRaw<D> kraw, vraw;
+  {
+    const int s0 = zigzag_slice(wave, 0) * 16;
+    col_raw_issue<D, true>(kraw, kb, rstride, s0, S, rot, rc, rs, lane);
+    col_raw_issue<D, false>(vraw, vb, rstride, s0, S, 0, rc, rs, lane);
+  }
+  for (int t = 0;; ++t) {
+    const int slice = zigzag_slice(wave, t);
+    if (slice >= nslices) break;
+    const int k0 = slice * 16;
+    const int mykey = k0 + (lane & 15);
+    const bool mykey_ok = key_ok(am, b, mykey, P, T, S);
+    bf16x8 kf[D / 32], vf[D / 32];
+    col_raw_finish<D, true>(kf, kraw, k0, S, rot, lane);
+    col_raw_finish<D, false>(vf, vraw, k0, S, 0, lane);
+    {
+      const int nxt = zigzag_slice(wave, t + 1);
+      if (nxt < nslices) {
+        col_raw_issue<D, true>(kraw, kb, rstride, nxt * 16, S, rot, rc, rs, lane);
+        col_raw_issue<D, false>(vraw, vb, rstride, nxt * 16, S, 0, rc, rs, lane);
+      }
+    }
+    f32x4 dk[D / 16], dv[D / 16];
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int qt = k0 / 64; qt < nqt; ++qt) {
+      f32x4 p[4], ds[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(qimg, qt * 4 + j, ks, lane), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(doimg, qt * 4 + j, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 64 + j * 16 + 4 * g + r;
+          const bool ok = mykey_ok && mykey <= q && q < S;
+          const float Lq = ok ? Lrow[q] : 0.f, Dq = ok ? Drow[q] : 0.f;
+          const float pv = ok ? __expf(s[r] * scale - Lq) : 0.f;
+          p[j][r] = pv;
+          ds[j][r] = pv * (dp[r] - Dq) * scale;
+        }
+      }
+      const bf16x8 p0 = pack_acc(p[0], p[1]), p1 = pack_acc(p[2], p[3]);
+      const bf16x8 d0 = pack_acc(ds[0], ds[1]), d1 = pack_acc(ds[2], ds[3]);
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, qt * 2, lane), p0, dv[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, qt * 2 + 1, lane), p1, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2, lane), d0, dk[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2 + 1, lane), d1, dk[dt], 0, 0, 0);
+      }
+    }
+    bf16_t* dkp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)mykey * rstride + D;
+    store_grad_unrot<D>(dkp, dk, rot, rc, rs, mykey, lane, mykey < S);
+    if (mykey < S) {
+      bf16_t* dvp = dkp + D;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) store4(dvp + dt * 16 + 4 * g, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
+    }
+  }
+}
+
+static bool attn_resident_fits(const AttnShape& sh, size_t* bytes) {
+  const size_t spad = (size_t)(sh.S + 63) / 64 * 64;
+  *bytes = spad * sh.D * 2 * 2;
+  return *bytes <= 160 * 1024;
+}
+static int g_attn_variant = 0;  // 0 automatic, 1 force the tiled kernels (tests)
+
+template <typename K>
+static void set_lds_attr(K kfn, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
                          hipStream_t st) {
+  size_t bytes;
+  if (g_attn_variant != 1 && attn_resident_fits(sh, &bytes)) {
+    dim3 grid(sh.H, sh.B), block(256);
+    if (sh.D == 64) {
+      set_lds_attr(attn_fwd_res_kernel<64>, bytes);
+      attn_fwd_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+    } else {
+      set_lds_attr(attn_fwd_res_kernel<128>, bytes);
+      attn_fwd_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+    }
+    return MAFED_OK;
+  }
   dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
   if (sh.D == 64) attn_fwd_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
   else attn_fwd_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
@@ -449,6 +842,24 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
 
 int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
                          const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st) {
+  size_t bytes;
+  if (g_attn_variant != 1 && attn_resident_fits(sh, &bytes)) {
+    dim3 grid(sh.H, sh.B), block(256);
+    if (sh.D == 64) {
+      set_lds_attr(attn_bwd_dq_res_kernel<64>, bytes);
+      set_lds_attr(attn_bwd_dkv_res_kernel<64>, bytes);
+      attn_bwd_dq_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
+                                                             (bf16_t*)dqkv, delta);
+      attn_bwd_dkv_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
+    } else {
+      set_lds_attr(attn_bwd_dq_res_kernel<128>, bytes);
+      set_lds_attr(attn_bwd_dkv_res_kernel<128>, bytes);
+      attn_bwd_dq_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
+                                                              (bf16_t*)dqkv, delta);
+      attn_bwd_dkv_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
+    }
+    return MAFED_OK;
+  }
   dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
   if (sh.D == 64) {
     attn_bwd_dq_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
@@ -461,5 +872,7 @@ int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, con
   }
   return MAFED_OK;
 }
+
+void attn_mfma_set_variant(int v) { g_attn_variant = v; }
 
 }  // namespace mafed

@@ -261,11 +261,16 @@ template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
                                                                        int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                        CT* __restrict__ C, GemmEpi epi, int tiles_n, int nwg) {
-  // block tile TM x TN x 64; WM x WN waves, each owning (MT*16) x (NT*16) outputs = MT x NT accumulators of 16x16
+  // block tile TM x TN x 64; WM x WN waves, each owning (MT*16) x (NT*16) outputs = MT x NT accumulators of 16x16.
+  // TM need not be a power of two: 144-row tiles make the tile count of every M = 9216 GEMM of the 410M / B32 step a
+  // multiple of the 512 resident blocks (9216 = 64 x 144), which 128-row tiles miss by up to 44 % (576 tiles = 1.125 rounds).
   constexpr int TM = WM * MT * 16, TN = WN * NT * 16, NW = WM * WN;
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_PER_WAVE = TM / 8 / NW, B_PER_WAVE = TN / 8 / NW;  // 1 KiB DMA instructions per wave per K-tile
-  static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && (TM / 8) % NW == 0 && (TN / 8) % NW == 0, "tile / wave count mismatch");
+  constexpr int NA = TM / 8, NB = TN / 8;                               // 1 KiB DMA instructions per operand per K-tile
+  constexpr int A_PER_WAVE = (NA + NW - 1) / NW, B_PER_WAVE = (NB + NW - 1) / NW;
+  static_assert(TM % 8 == 0 && TN % 8 == 0, "tile must be a multiple of the 8-row DMA piece");
+  static_assert(!A_KS || TM % 128 == 0, "the [k][row] image needs 128-row multiples");
+  static_assert(!B_KS || TN % 128 == 0, "the [k][row] image needs 128-row multiples");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,13 +282,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   }
   const int64_t m0 = (int64_t)(bid / tiles_n) * TM, n0 = (int64_t)(bid % tiles_n) * TN;
 
-  // per-lane DMA sources; k-tile advance is +64 elements (KC) or +64 rows (KS)
+  // per-lane DMA sources (piece j = wave + i * NW); k-tile advance is +64 elements (KC) or +64 rows (KS)
   const bf16_t* asrc[A_PER_WAVE];
   const bf16_t* bsrc[B_PER_WAVE];
 #pragma unroll
-  for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] = A + glds_src_off<A_KS, TM>(wave * A_PER_WAVE + i, lane, lda, m0);
+  for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] = A + glds_src_off<A_KS, TM>(wave + i * NW < NA ? wave + i * NW : 0, lane, lda, m0);
 #pragma unroll
-  for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] = B + glds_src_off<B_KS, TN>(wave * B_PER_WAVE + i, lane, ldb, n0);
+  for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] = B + glds_src_off<B_KS, TN>(wave + i * NW < NB ? wave + i * NW : 0, lane, ldb, n0);
   const int64_t a_step = A_KS ? 64 * lda : 64, b_step = B_KS ? 64 * ldb : 64;
 
   auto issue = [&](int stage, int kt) {
@@ -291,10 +296,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
     char* sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[i] + kt * a_step), (lds_void_ptr)(sa + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);
+      if (NA % NW == 0 || wave + i * NW < NA)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[i] + kt * a_step), (lds_void_ptr)(sa + (wave + i * NW) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < B_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + kt * b_step), (lds_void_ptr)(sb + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0);
+      if (NB % NW == 0 || wave + i * NW < NB)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + kt * b_step), (lds_void_ptr)(sb + (wave + i * NW) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[NT][MT];
@@ -306,14 +313,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   const int nkt = (int)(K / BK);
   issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
-    if (ABL != 1 && kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+    if (ABL != 6) __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
+    if (ABL != 1 && ABL != 5 && ABL != 6 && kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
     const char* sa = smem + (kt & 1) * STAGE;
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[MT], fb[NT];
-      if (ABL == 3) {
+      if (ABL == 3 || ABL == 5 || ABL == 6) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) { fb[t] = __builtin_bit_cast(bf16x8, make_uint4(kt, ks, t, lane)); asm volatile("" : "+v"(fb[t])); }
 #pragma unroll
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
     }
   }
-  if (ABL == 4) {  // timing only: no C traffic (one element per wave keeps the accumulators live)
+  if (ABL == 4 || ABL == 5 || ABL == 6) {  // timing only: no C traffic (one element per wave keeps the accumulators live)
     float sacc = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -347,13 +354,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
     if (lane == 0) Elem<CT>::store(C + (m0 + wm * MT * 16) * epi.ldc + n0 + wn * NT * 16, sacc);
     return;
   }
+  if constexpr (MT == 4 && NT == 4 && STAGE * 2 >= NW * 16384) {
+    // Epilogue through LDS: the accumulator layout gives each lane 4 columns of 16 different rows (8-byte bf16 stores in
+    // 32-byte row segments); re-read as 8 consecutive columns per lane so that C / aux / residual traffic moves in
+    // 128-256 contiguous bytes per row.  Wave-private 64x64 fp32 region, float4 slot XOR (row & 15): conflict-free both ways.
+    __syncthreads();  // every wave is done with the operand stages
+    float* reg = reinterpret_cast<float*>(smem) + wave * 4096;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int64_t m = m0 + (wm * MT + mt) * 16 + (lane & 15);
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = mt * 16 + (lane & 15);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int64_t n = n0 + (wn * NT + nt) * 16 + 4 * (lane >> 4);
-      epilogue_store4<CT, true>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
+      for (int nt = 0; nt < 4; ++nt) {
+        const int c4 = (nt * 4 + (lane >> 4)) ^ (row & 15);
+        *reinterpret_cast<f32x4*>(reg + row * 64 + c4 * 4) = acc[nt][mt];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), j = lane & 7;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      epilogue_store8<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v);
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int64_t m = m0 + (wm * MT + mt) * 16 + (lane & 15);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int64_t n = n0 + (wn * NT + nt) * 16 + 4 * (lane >> 4);
+        epilogue_store4<CT, true>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
+      }
     }
   }
 }
@@ -432,7 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring_kernel(int64_t M,
   constexpr int A_PER_WAVE = TM / 16 / NW, B_PER_WAVE = TN / 16 / NW;  // 1 KiB DMA instructions per wave per K-tile
   constexpr int LPT = A_PER_WAVE + B_PER_WAVE;                        // DMA instructions per wave per K-tile
   static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && (TM / 16) % NW == 0 && (TN / 16) % NW == 0, "tile / wave count mismatch");
-  static_assert(NS >= 3 && LPT * (NS - 2) <= 63, "ring depth out of range for a counted vmcnt");
+  static_assert(NS >= 2 && LPT * (NS - 2) <= 63, "ring depth out of range for a counted vmcnt");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -646,14 +679,22 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
     case 4: return launch_bf16_ring<2, 4, 8, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 256x256, ring of 4 (128 KiB)
     case 5: return launch_bf16_ring<2, 4, 8, 4, 5, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 256x256, ring of 5 (160 KiB)
     case 6: return launch_bf16_ring<2, 2, 4, 4, 5, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 128x128, ring of 5 (80 KiB)
+    case 11: if constexpr (!A_KS) return launch_bf16_glds<1, 4, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 4 waves of 144x32
+    case 12: if constexpr (!A_KS) return launch_bf16_glds<3, 2, 3, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 6 waves of 48x64
+    case 13: if constexpr (!A_KS) return launch_bf16_glds<1, 8, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x256, 8 waves of 144x32
     case 21: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 1>(M, N, K, A, lda, B, ldb, C, epi, st);  // ablations (timing only)
     case 22: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 2>(M, N, K, A, lda, B, ldb, C, epi, st);
     case 23: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 3>(M, N, K, A, lda, B, ldb, C, epi, st);
     case 24: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 4>(M, N, K, A, lda, B, ldb, C, epi, st);
+    case 25: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 5>(M, N, K, A, lda, B, ldb, C, epi, st);
+    case 26: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 6>(M, N, K, A, lda, B, ldb, C, epi, st);
+    case 9: return launch_bf16_ring<2, 2, 4, 4, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 128x128, BK 32, 2 stages (32 KiB): 4 blocks / CU
+    case 10: return launch_bf16_ring<2, 2, 4, 4, 3, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x128, BK 32, 3 stages (48 KiB): 3 blocks / CU
     case 7: return launch_bf16_pipe<2, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);      // 128x128, pipelined fragment reads
     case 8: return launch_bf16_pipe<2, 4, 8, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);      // 256x256, pipelined fragment reads
-    default: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);
+    default: break;
   }
+  return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);
 }
 
 template <bool A_KS, bool B_KS, typename CT>
@@ -718,10 +759,19 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
     const bool ok128 = (M % 128 == 0) && (N % 128 == 0), ok256 = (M % 256 == 0) && (N % 256 == 0), ok256x128 = (M % 256 == 0) && (N % 128 == 0);
     if (g_gemm_variant >= 10) {
       const int want = g_gemm_variant - 10;
-      if (((want == 0 || want == 3 || want == 6 || want == 7 || (want >= 21 && want <= 24)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
+      const bool ok144 = (M % 144 == 0) && (N % 128 == 0) && !a_ks, ok144x256 = (M % 144 == 0) && (N % 256 == 0) && !a_ks;
+      if (((want == 11 || want == 12) && ok144) || (want == 13 && ok144x256)) cfg = want;
+      else if (((want == 0 || want == 3 || want == 6 || want == 7 || want == 9 || want == 10 || (want >= 21 && want <= 26)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
       else if (ok128) cfg = 0;
-    } else if (ok128) {
-      cfg = 0;
+    } else {
+      // automatic: 128x128 tiles, unless 144-row tiles fill the 512 resident blocks much better (M = 9216 with N = 1024:
+      // 576 tiles = 1.125 rounds vs 512 = exactly one)
+      if (ok128) cfg = 0;
+      if ((M % 144 == 0) && (N % 128 == 0) && !a_ks) {
+        auto eff = [](int64_t t) { return (double)t / (double)(((t + 511) / 512) * 512); };
+        const double e144 = eff((M / 144) * (N / 128)), e128 = ok128 ? eff((M / 128) * (N / 128)) : 0.0;
+        if (e144 > 1.25 * e128) cfg = 11;
+      }
     }
   }
   if (cfg >= 0) {

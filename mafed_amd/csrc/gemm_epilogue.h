@@ -46,4 +46,70 @@ __device__ __forceinline__ void epilogue_store4(const GemmEpi& e, CT* __restrict
   store4(C + off, v);
 }
 
+// 8 consecutive columns n..n+7 of row m (n % 8 == 0): the coalesced form used after the accumulators went through LDS
+// (16-byte bf16 / 32-byte fp32 stores, 128/256 contiguous bytes per row per 8 lanes).
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const float4 a = load4(p), b = load4(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  store4(p, make_float4(v[0], v[1], v[2], v[3]));
+  store4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  uint4 r;
+  r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  r.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  r.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+
+template <typename CT>
+__device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict__ C, int64_t m, int64_t n, float (&v)[8]) {
+  const int64_t off = m * e.ldc + n;
+  if (e.bias) {
+    float b[8];
+    load8(e.bias + n, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (e.mode == MAFED_EPI_GELU) {
+    if (e.aux) store8(reinterpret_cast<CT*>(e.aux) + off, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gelu_erf_fast(v[i]);
+  } else if (e.mode == MAFED_EPI_GELU_BWD) {
+    float u[8];
+    load8(reinterpret_cast<const CT*>(e.aux) + off, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= gelu_erf_grad_fast(u[i]);
+  }
+  if (e.res1) {
+    float r[8];
+    load8(e.res1 + off, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (e.res2) {
+    float r[8];
+    load8(e.res2 + off, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (e.beta != 0.f) {
+    float c[8];
+    load8(C + off, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += e.beta * c[i];
+  }
+  store8(C + off, v);
+}
+
 }  // namespace mafed

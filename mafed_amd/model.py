@@ -289,12 +289,18 @@ class VLPythiaForCausalLM(nn.Module):
         return self
 
     # ---- streams ---------------------------------------------------------------------------------------------------
-    def side_stream(self):
-        """Second HIP stream of this replica: parameter-gradient GEMMs (dW = dY^T.X, bias column sums) run here, off the
-        critical dX chain, so their small grids (64-256 tiles at 410M) share the chip with the main stream's kernels."""
+    N_SIDE = 3
+
+    def side_streams(self):
+        """Extra HIP streams of this replica: parameter-gradient GEMMs (dW = dY^T.X, bias column sums) run here, off the
+        critical dX chain.  Their grids are small (64 / 192 / 256 / 256 tiles per layer at 410M): spread over three
+        streams they are co-resident and fill the 512 block slots together with the main stream's kernels."""
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat_params.device)
+            self._side = [torch.cuda.Stream(device=self.flat_params.device) for _ in range(self.N_SIDE)]
         return self._side
+
+    def side_stream(self):
+        return self.side_streams()[0]
 
     # ---- parameter views ---------------------------------------------------------------------------------------
     def sync_shadow(self):
@@ -494,17 +500,21 @@ class VLPythiaForCausalLM(nn.Module):
         if len(dhidden) > L and dhidden[L] is not None:
             raise NotImplementedError("gradient w.r.t. the post-final-LayerNorm hidden state is not on the MAFED path")
         main = torch.cuda.current_stream()
-        side = self.side_stream() if self.overlap_param_grads else None
-        keep: List[torch.Tensor] = []  # temporaries read by the side stream: kept alive until the join at the end
+        sides = self.side_streams() if self.overlap_param_grads else None
+        keep: List[torch.Tensor] = []  # temporaries read by the side streams: kept alive until the join at the end
+        rr = [0]
 
-        def on_side(fn, *tensors):
+        def on_side(fn, *tensors, k=None):
             """Run parameter-gradient work after everything queued on the main stream so far, off the dX chain."""
-            if side is None:
+            if sides is None:
                 fn()
                 return
+            if k is None:
+                k = rr[0] % len(sides)
+                rr[0] += 1
             ev = main.record_event()
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
+            with torch.cuda.stream(sides[k]):
+                sides[k].wait_event(ev)
                 fn()
             keep.extend(tensors)
 
@@ -516,8 +526,18 @@ class VLPythiaForCausalLM(nn.Module):
             on_side(run, dY, X)
 
         def ready(i):
-            if self.grad_ready_hook is not None:
-                on_side(lambda: self.grad_ready_hook(i))
+            """Bucket hook: fires on side stream 0 once every side stream has finished the gradients queued so far."""
+            if self.grad_ready_hook is None:
+                return
+            if sides is None:
+                self.grad_ready_hook(i)
+                return
+            evs = [st.record_event() for st in sides[1:]]
+            def run():
+                for e in evs:
+                    sides[0].wait_event(e)
+                self.grad_ready_hook(i)
+            on_side(run, k=0)
 
         dx = None  # gradient w.r.t. the residual stream leaving the current layer, fp32 [rows, h]
         if dloss is not None and sv["loss"] is not None:
@@ -579,8 +599,9 @@ class VLPythiaForCausalLM(nn.Module):
             du0 = ops.gemm(dimg, w("vision_embed_tokens.2.weight"), False, False, epilogue=EPI_GELU_BWD, aux=u0)
             wgrad(du0, fc, "vision_embed_tokens.0.weight", "vision_embed_tokens.0.bias")
         ready(-1)
-        if side is not None:
-            main.wait_stream(side)  # gradients complete (and `keep` safe to release) from the main stream's point of view
+        if sides is not None:
+            for st in sides:
+                main.wait_stream(st)  # gradients complete (and `keep` safe to release) from the main stream's point of view
         keep.clear()
 
 

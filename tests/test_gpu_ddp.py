@@ -1,0 +1,121 @@
+"""GPU, two ranks sharing the box's one GPU over gloo (RCCL refuses two ranks on one device): the data-parallel step --
+hand-scheduled backward on two streams, bucket hooks, side-stream all-reduce, clip, AdamW -- must equal a single
+process that averages the two ranks' gradients itself."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import vlpythia_ref as R
+from tests.helpers import TINY, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(cfg, sd, dtype=torch.float32):
+    from mafed_amd import VLPythiaConfig, VLPythiaForCausalLM
+    mc = VLPythiaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                        vision_hidden_size=cfg.vision_hidden_size, num_vision_tokens=cfg.num_vision_tokens)
+    m = VLPythiaForCausalLM(mc, compute_dtype=dtype, device="cuda")
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def _make(cfg, sd, tsd, ddp, rank_batches):
+    from mafed_amd import FeatureDistillation, Trainer
+    t = TINY["m64"]
+    model, teacher = _build(cfg, sd), _build(cfg, tsd)
+    opts = types.SimpleNamespace(tasks=["a", "b"], batch_size=t["B"], seed=3, pin_mem=False, accumulate_grad_batches=2)
+    fd = FeatureDistillation(memory_size=10, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                             distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                             gamma=0.5, distillation_layer=None)
+    fd._update_model(teacher)
+    fd.task_id = 1
+    fd.num_vision_tokens = cfg.num_vision_tokens
+    conf = types.SimpleNamespace(accumulate_grad_batches=2, replay_interval=2, grad_norm=2.0, learning_rate=1e-3, betas=(0.9, 0.98),
+                                 weight_decay=0.01, optim="adamw", warmup_steps=1, total_steps=10)
+    tr = Trainer(model, fd, conf, task_id=1, ddp=ddp, bucket_mb=0.05)
+    return model, fd, tr
+
+
+def _batches(cfg, rank):
+    t = TINY["m64"]
+    return [{k: v.cuda() for k, v in R.make_batch(cfg, t["B"], t["T"], seed=100 + 10 * rank + i, pad=True, n_answer=3).items()} for i in range(4)]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = tiny_cfg("m64")
+        sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
+        tsd = R.perturb(sd, seed=22, std=5e-3)
+        model, fd, tr = _make(cfg, sd, tsd, True, None)
+        bs = _batches(cfg, rank)
+        gns = []
+        for i in range(4):  # accumulate 2, replay every 2nd micro-batch: two optimiser steps
+            fd.mem_dataloader = [dict(bs[(i + 1) % 4])]
+            rec = tr.step(dict(bs[i]), i)
+            if rec["stepped"]:
+                gns.append(float(rec["grad_norm"]))
+        torch.cuda.synchronize()
+        q.put((rank, gns, model.flat_params.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ddp_step_equals_mean_of_rank_gradients():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+    # replicas stay identical
+    assert np.array_equal(res[0][2], res[1][2])
+    assert res[0][1] == res[1][1]
+    # single-process emulation: run both ranks' micro-batches, average gradients by hand before the optimiser step
+    cfg = tiny_cfg("m64")
+    sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
+    tsd = R.perturb(sd, seed=22, std=5e-3)
+    model, fd, tr = _make(cfg, sd, tsd, False, None)
+    bs = [_batches(cfg, 0), _batches(cfg, 1)]
+    gns = []
+    for step in range(2):
+        acc = torch.zeros_like(model.flat_grads)
+        for rank in range(2):
+            model.flat_grads.zero_()
+            for j in range(2):
+                i = 2 * step + j
+                fd.mem_dataloader = [dict(bs[rank][(i + 1) % 4])]
+                loss, _ = tr.training_step(dict(bs[rank][i]), i)
+                (loss / 2).backward()
+            acc += model.flat_grads
+        model.flat_grads.copy_(acc / 2)
+        gns.append(float(tr.optimizer.clip_grad_norm_(2.0)))
+        tr.optimizer.step()
+        tr.scheduler.step()
+        tr.optimizer.zero_grad()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(res[0][1], gns, rtol=1e-5)
+    np.testing.assert_allclose(res[0][2], model.flat_params.detach().cpu().numpy(), rtol=0, atol=2e-6)

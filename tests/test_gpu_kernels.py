@@ -56,9 +56,9 @@ def _int_mat(shape, g, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23])
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320), (288, 512, 192), (576, 384, 128)])
 def test_gemm_bf16_exact_integers(tA, tB, M, N, K, variant):
     """Small-integer operands are exact in bf16 and the fp32 accumulator: any wrong fragment / transposing-read /
     swizzle mapping shows up as a hard mismatch (asymmetric data)."""
@@ -257,9 +257,21 @@ def test_attention_f32(B, P, T, H, D):
     assert_close(dqkv.view(B, S, H, 3, D), qd.grad, 5e-5, "attn dqkv")
 
 
-@pytest.mark.parametrize("B,P,T,H,D", [(2, 8, 6, 2, 64), (2, 40, 24, 2, 128), (3, 70, 13, 2, 64), (2, 256, 32, 4, 64), (1, 200, 57, 2, 128)])
-def test_attention_bf16_mfma(B, P, T, H, D):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,P,T,H,D", [(2, 8, 6, 2, 64), (2, 40, 24, 2, 128), (3, 70, 13, 2, 64), (2, 256, 32, 4, 64), (1, 200, 57, 2, 128),
+                                       (1, 600, 41, 1, 64), (2, 129, 1, 2, 64)])
+def test_attention_bf16_mfma(B, P, T, H, D, variant):
+    """variant 0: one-block-per-head resident kernels where K/V fit in LDS (S <= 640 at D = 64), else tiled; 1: tiled only."""
     ops = _ops()
+    from mafed_amd import _lib
+    _lib.load().mafed_attn_set_variant(variant)
+    try:
+        _attention_bf16_case(ops, B, P, T, H, D)
+    finally:
+        _lib.load().mafed_attn_set_variant(0)
+
+
+def _attention_bf16_case(ops, B, P, T, H, D):
     qkv, am, dout, rot, cos, sin = _attn_case(B, P, T, H, D, seed=3 * D + T)
     S = P + T
     am_full = torch.cat([torch.ones(B, P, dtype=torch.int64), am], 1)

@@ -21,6 +21,8 @@ SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
     ("wqkv  TN", True, False, 3072, 1024, M, torch.float32),
     ("wdns  TN", True, False, 1024, 1024, M, torch.float32),
     ("head  NT", False, True, 1024, 50304, 1024, torch.bfloat16),
+    ("dlnf  NN", False, False, 1024, 1024, 50304, torch.bfloat16),
+    ("proj  NT", False, True, 8192, 1024, 1024, torch.bfloat16),
 ]
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
 lib = _lib.load()
