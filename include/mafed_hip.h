@@ -174,7 +174,9 @@ int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype ds
 /* y = gelu_erf(x) elementwise (used by tests; the product path fuses GELU into mafed_gemm) */
 int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream);
 
-/* test / tuning hook: 0 = automatic kernel choice, 1 = force the register-staged MFMA GEMM (the ragged-shape kernel) */
+/* test / tuning hook: 0 = automatic kernel choice, 1 = force the register-staged MFMA GEMM (the ragged-shape kernel),
+ * 10 + c = force LDS-DMA tile configuration c; 100 = automatic split-K for accumulate-only outputs, 101 = no split-K,
+ * 100 + n = force n K-splits where legal */
 int mafed_gemm_set_variant(int variant);
 
 /* test / tuning hook: 0 = automatic (one-block-per-head "resident" kernels when K/V fit in LDS), 1 = tiled kernels only */

@@ -231,12 +231,15 @@ __device__ __forceinline__ int64_t glds_src_off(int j, int lane, int64_t ld, int
     constexpr int RB = 2 * R;                  // bytes per k-row of the image
     const int p = j * 1024 + lane * 16;
     const int k = p / RB, within = p % RB;
-    const int logical16 = (within >> 5) ^ ks_f(k);
+    const int logical16 = (within >> 5) ^ (ks_f(k) & (R / 16 - 1));
     return (int64_t)k * ld + r0 + logical16 * 16 + ((within >> 4) & 1) * 8;
   }
 }
+// [k][R rows] image: 32-byte chunk index XOR f(k), masked to the R/16 chunks of a k-row (R = 64: 2-way conflicts remain)
 template <int R>
-__device__ __forceinline__ int lds_off_ks_r(int k, int r16, int byte_in_32) { return k * (2 * R) + ((r16 ^ ks_f(k)) << 5) + byte_in_32; }
+__device__ __forceinline__ int lds_off_ks_r(int k, int r16, int byte_in_32) {
+  return k * (2 * R) + ((r16 ^ (ks_f(k) & (R / 16 - 1))) << 5) + byte_in_32;
+}
 
 template <bool KS, int R>
 __device__ __forceinline__ bf16x8 glds_read_frag(const char* __restrict__ img, int rt, int ks, int lane) {
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   constexpr int NA = TM / 8, NB = TN / 8;                               // 1 KiB DMA instructions per operand per K-tile
   constexpr int A_PER_WAVE = (NA + NW - 1) / NW, B_PER_WAVE = (NB + NW - 1) / NW;
   static_assert(TM % 8 == 0 && TN % 8 == 0, "tile must be a multiple of the 8-row DMA piece");
-  static_assert(!A_KS || TM % 128 == 0, "the [k][row] image needs 128-row multiples");
-  static_assert(!B_KS || TN % 128 == 0, "the [k][row] image needs 128-row multiples");
+  static_assert(!A_KS || TM == 64 || TM % 128 == 0, "the [k][row] image needs 64 or 128-row multiples");
+  static_assert(!B_KS || TN == 64 || TN % 128 == 0, "the [k][row] image needs 64 or 128-row multiples");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,7 +313,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = (int)(K / BK);
+  // split-K (gridDim.y > 1, accumulate-only fp32 outputs): this block owns K-tiles [kt0, kt0 + nkt)
+  const int nkt_all = (int)(K / BK);
+  const int kt0 = (int)((int64_t)nkt_all * blockIdx.y / gridDim.y);
+  const int nkt = (int)((int64_t)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
+#pragma unroll
+  for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] += kt0 * a_step;
+#pragma unroll
+  for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] += kt0 * b_step;
   issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     if (ABL != 6) __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
@@ -370,6 +380,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (gridDim.y > 1) {
+      // split-K partial: C += acc with fp32 atomics, one 256-byte row segment per wave-instruction (the full-rate shape
+      // of MI355X_MICROARCH "Global float atomics"); the gradient buffer already holds the running sum (beta = 1)
+      float* cbase = reinterpret_cast<float*>(C) + (m0 + wm * 64) * epi.ldc + n0 + wn * 64 + lane;
+#pragma unroll 8
+      for (int row = 0; row < 64; ++row) {
+        const float v = reg[row * 64 + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
+        atomicAdd(cbase + (int64_t)row * epi.ldc, v);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), j = lane & 7;
@@ -377,6 +398,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       epilogue_store8<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v);
+    }
+  } else if constexpr (MT == 9 && NT == 2 && WM == 1 && STAGE * 2 >= NW * 10240) {
+    // 144 x 32 wave tile: same idea in two passes (row tiles 0-4, then 5-8) through a wave-private 80 x 32 fp32 region
+    __syncthreads();
+    float* reg = reinterpret_cast<float*>(smem) + wave * 2560;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int mt0 = pass * 5, nmt = pass == 0 ? 5 : 4;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        if (t < nmt) {
+          const int row = t * 16 + (lane & 15);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int c4 = (nt * 4 + (lane >> 4)) ^ (row & 7);
+            *reinterpret_cast<f32x4*>(reg + row * 32 + c4 * 4) = acc[nt][mt0 + t];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        if (it < nmt) {
+          const int row = it * 16 + (lane >> 2), j = lane & 3;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j) ^ (row & 7)) << 2));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j + 1) ^ (row & 7)) << 2));
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          epilogue_store8<CT>(epi, C, m0 + mt0 * 16 + row, n0 + wn * 32 + 8 * j, v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   } else {
 #pragma unroll
@@ -391,6 +443,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   }
 }
 
+static int g_gemm_nsplit = 1;  // set by the dispatcher for the next launch_bf16_glds<2,2,4,4,...> (split-K, accumulate-only)
+
 template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0>
 static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                             const GemmEpi& epi, hipStream_t st) {
@@ -403,8 +457,9 @@ static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int6
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  kfn<<<dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi, (int)tn,
-                                                             (int)nwg);
+  const int nsplit = (MT == 4 && NT == 4 && WM == 2 && WN == 2) ? g_gemm_nsplit : 1;
+  kfn<<<dim3((unsigned)nwg, (unsigned)nsplit), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi,
+                                                                               (int)tn, (int)nwg);
   return MAFED_OK;
 }
 
@@ -682,6 +737,8 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
     case 11: if constexpr (!A_KS) return launch_bf16_glds<1, 4, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 4 waves of 144x32
     case 12: if constexpr (!A_KS) return launch_bf16_glds<3, 2, 3, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 6 waves of 48x64
     case 13: if constexpr (!A_KS) return launch_bf16_glds<1, 8, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x256, 8 waves of 144x32
+    case 14: return launch_bf16_glds<2, 2, 4, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x64, 4 waves of 64x32 (48 KiB: 3 blocks / CU)
+    case 15: return launch_bf16_glds<2, 2, 2, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 64x128
     case 21: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 1>(M, N, K, A, lda, B, ldb, C, epi, st);  // ablations (timing only)
     case 22: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 2>(M, N, K, A, lda, B, ldb, C, epi, st);
     case 23: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 3>(M, N, K, A, lda, B, ldb, C, epi, st);
@@ -720,7 +777,12 @@ using namespace mafed;
 
 // test / tuning hook: 0 = automatic, 1 = force the register-staged kernel
 static int g_gemm_variant = 0;
-extern "C" int mafed_gemm_set_variant(int v) { g_gemm_variant = v; return MAFED_OK; }
+static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
+extern "C" int mafed_gemm_set_variant(int v) {
+  if (v >= 100) { g_gemm_split = v - 100; return MAFED_OK; }  // 100 = automatic split-K, 101 = off, 100 + n = force n
+  g_gemm_variant = v;
+  return MAFED_OK;
+}
 
 extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                           const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
@@ -761,6 +823,8 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
       const int want = g_gemm_variant - 10;
       const bool ok144 = (M % 144 == 0) && (N % 128 == 0) && !a_ks, ok144x256 = (M % 144 == 0) && (N % 256 == 0) && !a_ks;
       if (((want == 11 || want == 12) && ok144) || (want == 13 && ok144x256)) cfg = want;
+      else if (want == 14 && (M % 128 == 0) && (N % 64 == 0)) cfg = 14;
+      else if (want == 15 && (M % 64 == 0) && (N % 128 == 0)) cfg = 15;
       else if (((want == 0 || want == 3 || want == 6 || want == 7 || want == 9 || want == 10 || (want >= 21 && want <= 26)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
       else if (ok128) cfg = 0;
     } else {
@@ -770,9 +834,17 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
       if ((M % 144 == 0) && (N % 128 == 0) && !a_ks) {
         auto eff = [](int64_t t) { return (double)t / (double)(((t + 511) / 512) * 512); };
         const double e144 = eff((M / 144) * (N / 128)), e128 = ok128 ? eff((M / 128) * (N / 128)) : 0.0;
-        if (e144 > 1.25 * e128) cfg = 11;
+        if (e144 >= e128) cfg = 11;  // measured >= the 128-row tile on every M = 9216 shape once both use the LDS-staged epilogue
       }
     }
+  }
+  g_gemm_nsplit = 1;
+  if (cfg == 0 && c_dtype == MAFED_F32 && beta == 1.0f && !bias && epilogue == MAFED_EPI_NONE && !res1 && !res2 && g_gemm_split != 1) {
+    // weight-gradient GEMMs (dW += dY^T.X): few output tiles, very long K.  Split K so that the grid fills the chip.
+    const int64_t tiles = (M / 128) * (N / 128), nkt = K / 64;
+    int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? 4 : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
+    while (ns > 1 && nkt / ns < 8) ns >>= 1;
+    g_gemm_nsplit = ns;
   }
   if (cfg >= 0) {
 #define GOG(AKS, BKS)                                                                                                       \

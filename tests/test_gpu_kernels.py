@@ -56,7 +56,7 @@ def _int_mat(shape, g, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23])
+@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25])
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320), (288, 512, 192), (576, 384, 128)])
 def test_gemm_bf16_exact_integers(tA, tB, M, N, K, variant):
@@ -111,6 +111,26 @@ def test_gemm_epilogues(dt):
     F.gelu(uf).sum().backward()
     y = ops.gemm(Ad, Wd, False, True, epilogue=ops.EPI_GELU_BWD, aux=ud)
     assert_close(y.float(), (Af @ Wf.t()) * uf.grad, tol, "gelu_bwd")
+
+
+@pytest.mark.parametrize("split", [100, 101, 102, 104, 108])
+def test_gemm_split_k_accumulate(split):
+    """dW += dY^T.X with K split over blockIdx.y and fp32 atomics into the running gradient (100 = automatic choice)."""
+    ops = _ops()
+    from mafed_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 256, 384, 2048
+    A = _int_mat((K, M), g)
+    B = _int_mat((K, N), g)
+    c0 = _int_mat((M, N), g, -50, 50)
+    out = c0.clone().to(DEV)
+    _lib.load().mafed_gemm_set_variant(split)
+    try:
+        ops.gemm(A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16), True, False, out=out, beta=1.0)
+    finally:
+        _lib.load().mafed_gemm_set_variant(100)
+    ref = c0.double() + A.double().t() @ B.double()
+    assert maxerr(out, ref) == 0.0
 
 
 def test_gemm_rejects_bad_arguments():

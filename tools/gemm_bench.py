@@ -33,12 +33,14 @@ for name, tA, tB, m, n, k, od in SHAPES:
     B = torch.randn((n, k) if tB else (k, n), device=dev, generator=g).to(torch.bfloat16)
     out = torch.zeros((m, n), dtype=od, device=dev)
     ref = None
+    beta = 1.0 if (tA and od == torch.float32) else 0.0   # weight-gradient GEMMs accumulate into the gradient buffer
     for v in variants:
         lib.mafed_gemm_set_variant(v)
-        ops.gemm(A, B, tA, tB, out=out)
+        out.zero_()
+        ops.gemm(A, B, tA, tB, out=out, beta=beta)
         if ref is None:
             ref = out.float().clone()
-        elif v < 30:
+        elif v < 30 or v >= 100:
             err = (out.float() - ref).abs().max().item()
             assert err <= 1e-2 * ref.abs().max().item(), (name, v, err)
     times = {v: [] for v in variants}
@@ -48,7 +50,7 @@ for name, tA, tB, m, n, k, od in SHAPES:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                ops.gemm(A, B, tA, tB, out=out)
+                ops.gemm(A, B, tA, tB, out=out, beta=beta)
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 10)
@@ -56,3 +58,4 @@ for name, tA, tB, m, n, k, od in SHAPES:
     line = f"{name} {m}x{n}x{k}: " + "  ".join(f"v{v}: {min(t)*1e3:7.1f} us {fl/min(t)/1e9:7.1f} TF" for v, t in times.items())
     print(line, flush=True)
 lib.mafed_gemm_set_variant(0)
+lib.mafed_gemm_set_variant(100)
