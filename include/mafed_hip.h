@@ -79,8 +79,9 @@ int mafed_layernorm_fwd(const float* x, int64_t rows, int h, float eps,
  * gradient flowing around the layer); dx fp32 [rows,h] (may alias dres).  dw1/db1/dw2/db2 fp32 [h], accumulated.
  * Optional fused distillation-gradient injection (the hidden state this LN normalises is a distilled one,
  * mafed/methods/distillation.py:237-249 backward): if teacher != NULL,
- *   dx[row,:] += inj_scale[row_class] * (x - teacher)   with row_class from (row % S): <P image, text-valid, pad=none
- * where inj_scale_host = {lang_scale, vision_scale} already contains 2/h * coeff * weight / count * upstream grad. */
+ *   dx[row,:] += inj_mul * inj_scale[row_class] * (x - teacher)   with row_class from (row % S): <P image, text-valid, pad=none
+ * where inj_scale_dev = {lang, vision} = d(loss)/d(sum_lang d), d(loss)/d(sum_vision d) (coeff * weight / count * upstream grad,
+ * left on the device by the loss algebra) and inj_mul = 2/h (MSE). */
 size_t mafed_layernorm_bwd_workspace_bytes(int64_t rows, int h);
 int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype,
                         const float* x, const float* mean, const float* rstd,
@@ -88,7 +89,7 @@ int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype,
                         const float* dres, float* dx, void* dx_lp,
                         float* dw1, float* db1, float* dw2, float* db2,
                         const float* teacher, const int64_t* attention_mask, int S, int P, int T,
-                        const float* inj_scale_dev /* [2] device: {lang, vision} or NULL */,
+                        const float* inj_scale_dev /* [2] device: {lang, vision} or NULL */, float inj_mul /* host factor, e.g. 2/h */,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- attention (tf:154-236 eager path / flash-attn-2 wheel, README.md:16) ------------------------------------

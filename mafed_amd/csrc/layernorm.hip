@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
                                                             const float* __restrict__ dres, float* __restrict__ dx,
                                                             DyT* __restrict__ dx_lp, const float* __restrict__ teacher,
                                                             const int64_t* __restrict__ attention_mask, int S, int P, int T,
-                                                            const float* __restrict__ inj_scale, float* __restrict__ partial) {
+                                                            const float* __restrict__ inj_scale, float inj_mul,
+                                                            float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [3 waves][NP][h] staging for the cross-wave sum
   constexpr int NP = DUAL ? 4 : 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
     if (DUAL) g2[i] = (c < h) ? load4(w2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float ls = 0.f, vs = 0.f;
-  if (teacher) { ls = inj_scale[0]; vs = inj_scale[1]; }
+  if (teacher) { ls = inj_scale[0] * inj_mul; vs = inj_scale[1] * inj_mul; }
   for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
     const float mu = mean[row], rs = rstd[row];
     float4 xh[NV], g[NV];
@@ -266,7 +267,7 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
                                    const float* rstd, const float* w1, const float* w2, int64_t rows, int h,
                                    const float* dres, float* dx, void* dx_lp, float* dw1, float* db1, float* dw2, float* db2,
                                    const float* teacher, const int64_t* attention_mask, int S, int P, int T,
-                                   const float* inj_scale_dev, void* workspace, size_t workspace_bytes, void* stream) {
+                                   const float* inj_scale_dev, float inj_mul, void* workspace, size_t workspace_bytes, void* stream) {
   MAFED_CHECK_ARG(dy1 && x && mean && rstd && w1 && dx && dw1 && db1, "layernorm_bwd: null pointer");
   MAFED_CHECK_ARG(h > 0 && h % 4 == 0, "layernorm_bwd: h=%d must be a positive multiple of 4", h);
   const bool dual = dy2 != nullptr;
@@ -292,7 +293,7 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
     auto kfn = layernorm_bwd_kernel<NV, T, DUAL>;                                                                        \
     if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     kfn<<<grid, block, lds_bytes, st>>>((const T*)dy1, (const T*)dy2, x, mean, rstd, w1, w2, rows, h, dres, dx, (T*)dx_lp, \
-                                        teacher, attention_mask, S, P, T_, inj_scale_dev, partial);                      \
+                                        teacher, attention_mask, S, P, T_, inj_scale_dev, inj_mul, partial);                      \
   } while (0)
   const int T_ = T;
 #define DISPATCH_D(NV, TT) \

@@ -46,6 +46,29 @@ class _DistillSumsFn(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+class _FusedDistillSumsFn(torch.autograd.Function):
+    """Same sums as _DistillSumsFn for the native model, but the backward materialises nothing: it leaves
+    d loss / d sums (one device row per layer) in the model's activation record and the model's own backward adds
+    coef * 2/h * (x - teacher) to the residual-stream gradient inside the LayerNorm-backward kernel of that layer
+    (mafed_layernorm_bwd, teacher != NULL) -- no per-layer gradient tensor, no separate add / cast pass."""
+
+    @staticmethod
+    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, *student):
+        nl = len(student)
+        out = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
+        for l in range(nl):
+            ops.distill_fwd(student[l], teacher[l], attention_mask, P, False, out=out[l])
+        ctx.sv, ctx.layers, ctx.teacher = sv, list(layers), list(teacher)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        ctx.sv["inject"] = {layer: (ctx.teacher[k], g[k]) for k, layer in enumerate(ctx.layers)}
+        ctx.sv = None
+        return (torch.zeros((), device=g.device), None, None, None, None, None) + (None,) * len(ctx.layers)
+
+
 class _DistillClsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, t):
@@ -94,6 +117,7 @@ class FeatureDistillation(CLStrategy):
         self.num_vision_tokens = 256  # hard-coded upstream (distillation.py:73); instance attribute, settable
         self.mem_dataloader = None
         self.overlap_teacher = True
+        self.fused_distill = True  # MSE distillation gradient injected inside the model's LayerNorm-backward kernels
         self._prefetched = None
         self.last_layer_losses: Optional[torch.Tensor] = None  # [n_layers] device tensor of the last distill() call
         self.last_modality_losses: Optional[torch.Tensor] = None  # [n_layers, 2] (lang, vision)
@@ -225,7 +249,11 @@ class FeatureDistillation(CLStrategy):
             batch["lang_masks"], batch["image_masks"] = lm, im  # side effect kept (distillation.py:139,144)
             students = [output.hidden_states[l] for l in layers]
             teachers = [past[l] for l in layers]
-            sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
+            mctx = getattr(output, "mafed_ctx", None)
+            if self.fused_distill and not self._cosine and mctx is not None:
+                sums = _FusedDistillSumsFn.apply(mctx[1], am, P, teachers, mctx[0], layers, *students)  # [nl, 4]
+            else:
+                sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
             lang = sums[:, 0] / sums[:, 2]
             vis = sums[:, 1] / sums[:, 3]
             lw, vw = self.loss_weights.modality_weight_vectors(sums[0, 2].detach(), sums[0, 3].detach(), layers, dev)

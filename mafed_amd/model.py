@@ -81,6 +81,7 @@ class CausalLMOutput:
     past_key_values: Any = None
     hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
     attentions: Any = None
+    mafed_ctx: Any = None  # (activation record, hook tensor) for the fused distillation path of mafed_amd's own plugin
 
     def __getitem__(self, i):
         return tuple(v for v in (self.loss, self.logits, self.hidden_states) if v is not None)[i]
@@ -380,14 +381,17 @@ class VLPythiaForCausalLM(nn.Module):
         labels = labels.to(dev, torch.int64).contiguous() if labels is not None else None
         feats = feats.to(dev).contiguous()
         if torch.is_grad_enabled():
-            outs = _ModelFn.apply(self._anchor, self, feats, input_ids, attention_mask, labels, want_h)
+            ctx_box: List[Any] = []
+            outs = _ModelFn.apply(self._anchor, self, feats, input_ids, attention_mask, labels, want_h, ctx_box)
             loss = outs[0] if labels is not None else None
-            logits, hs = outs[1], tuple(outs[2:]) if want_h else None
+            logits, hs = outs[1], tuple(outs[3:]) if want_h else None
+            mctx = (ctx_box[0], outs[2]) if want_h else None
         else:
+            mctx = None
             st = self._engine_forward(feats, input_ids, attention_mask, labels, want_h, train=False)
             loss = st["loss"].reshape(()) if st["loss"] is not None else None
             logits, hs = st["logits"], tuple(st["hidden"]) if want_h else None
-        out = CausalLMOutput(loss=loss, logits=logits, hidden_states=hs)
+        out = CausalLMOutput(loss=loss, logits=logits, hidden_states=hs, mafed_ctx=mctx)
         if return_dict is False:
             return tuple(v for v in (out.loss, out.logits, out.hidden_states) if v is not None)
         return out
@@ -499,6 +503,7 @@ class VLPythiaForCausalLM(nn.Module):
         dev = self.flat_params.device
         if len(dhidden) > L and dhidden[L] is not None:
             raise NotImplementedError("gradient w.r.t. the post-final-LayerNorm hidden state is not on the MAFED path")
+        inject = sv.get("inject")  # {layer: (teacher hidden state, device [4] = d loss / d {sum_lang, sum_vision, ., .})}
         main = torch.cuda.current_stream()
         sides = self.side_streams() if self.overlap_param_grads else None
         keep: List[torch.Tensor] = []  # temporaries read by the side streams: kept alive until the join at the end
@@ -559,8 +564,13 @@ class VLPythiaForCausalLM(nn.Module):
                 ext = ext.reshape(rows, h)
                 dx = ext.to(torch.float32) if dx is None else dx.add_(ext)
                 dy = None
+            inj = inject.get(i) if inject else None
             if dx is None:
-                continue  # nothing flows into this layer's output (e.g. distillation of shallow layers only)
+                # nothing flows into this layer's output (distillation of shallower layers only): its own backward is skipped,
+                # but a distilled hidden_states[i] (this layer's input) still starts the gradient for the layers below
+                if inj is not None:
+                    dx = ops.distill_bwd(sv["layers"][i]["x"].view(B, S, h), inj[0], am, P, inj[1]).view(rows, h)
+                continue
             if dy is None:
                 dy = dx if cd == torch.float32 else ops.cast(dx, cd)
             pre = f"gpt_neox.layers.{i}."
@@ -582,7 +592,9 @@ class VLPythiaForCausalLM(nn.Module):
                                        self._p(pre + "post_attention_layernorm.weight"), dx,
                                        g(pre + "input_layernorm.weight"), g(pre + "input_layernorm.bias"),
                                        g(pre + "post_attention_layernorm.weight"), g(pre + "post_attention_layernorm.bias"),
-                                       want_lp=(cd != torch.float32))
+                                       want_lp=(cd != torch.float32),
+                                       teacher=inj[0].view(rows, h) if inj is not None else None, attention_mask=am if inj is not None else None,
+                                       S=S, P=P, inj_scale=inj[1] if inj is not None else None, inj_mul=2.0 / h)
             if cd == torch.float32:
                 dy = dx
             if taps is not None and i in taps:
@@ -609,19 +621,22 @@ class _ModelFn(torch.autograd.Function):
     """The whole model as one autograd node: outputs (loss, logits, *hidden_states)."""
 
     @staticmethod
-    def forward(ctx, anchor, model: VLPythiaForCausalLM, feats, input_ids, attention_mask, labels, want_hidden):
+    def forward(ctx, anchor, model: VLPythiaForCausalLM, feats, input_ids, attention_mask, labels, want_hidden, ctx_box):
         sv = model._engine_forward(feats, input_ids, attention_mask, labels, want_hidden, train=True)
         ctx.model, ctx.sv = model, sv
+        ctx_box.append(sv)
         ctx.set_materialize_grads(False)  # outputs nobody differentiated arrive as None, not as zero tensors
         loss = sv["loss"].reshape(()).clone() if sv["loss"] is not None else torch.zeros((), device=anchor.device)
-        outs = [loss, sv["logits"].detach()]
+        # outs[2] is a 0-dim "hook": the fused distillation node takes it as an input so that this node's backward runs
+        # (after the distillation node has left its per-layer coefficients in sv["inject"]) even without a CE gradient
+        outs = [loss, sv["logits"].detach(), torch.zeros((), device=anchor.device)]
         ctx.mark_non_differentiable(outs[1])
         if want_hidden:
             outs += [x.detach() for x in sv["hidden"]]  # aliases: no reference cycle through ctx
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dloss, dlogits, *dhidden):
+    def backward(ctx, dloss, dlogits, dhook, *dhidden):
         sv = ctx.sv
         ctx.sv = None
         if sv is None:
@@ -629,7 +644,8 @@ class _ModelFn(torch.autograd.Function):
         if sv["loss"] is None:
             dloss = None
         ctx.model._engine_backward(sv, dloss, list(dhidden))
-        return (None,) * 7
+        sv.pop("inject", None)
+        return (None,) * 8
 
 
 model_architecture = {"vlpythia": VLPythiaForCausalLM}

@@ -125,6 +125,30 @@ def test_mafed_replay_vs_reference_golden(name, vname):
     check_named_grads(model, g, pre, TOL)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("replay_coeff", [0.7, 0.0])
+def test_mafed_fused_and_generic_distillation_paths(fused, replay_coeff):
+    """MSE distillation gradient injected inside the LayerNorm-backward kernels (fused) vs materialised per layer through
+    plain autograd (generic; what the reference's own plugin code would exercise), with and without the replay CE term."""
+    cfg, sd, tsd, batch, g = golden_setup("m64")
+    model, teacher = build_model(cfg, sd), build_model(cfg, tsd)
+    fd, spec = make_fd(cfg, "equal_discounted_g09_mse", g, teacher, batch, batch["input_ids"].shape[0])
+    fd.replay_coeff = replay_coeff
+    fd.fused_distill = fused
+    fd.mem_dataloader = [to_dev(batch)]
+    model.zero_grad()
+    loss, _ = fd.replay(model)
+    loss.backward()
+    spec.replay_coeff = replay_coeff
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, _, _ = R.mafed_replay_loss(params, tsd, batch, cfg, spec, task_id=1)
+    ref_loss.backward()
+    close(loss, float(ref_loss), TOL, "loss")
+    names, norms = grad_norms(model, cfg)
+    refn = np.array([float(params[k].grad.norm()) if params[k].grad is not None else 0.0 for k in names])
+    close(norms, refn, TOL, "grad norms")
+
+
 def test_layer_strategy_errors_match_reference():
     from mafed_amd import FeatureDistillation
     opts = types.SimpleNamespace(tasks=["a", "b"], batch_size=2, seed=1, pin_mem=False, accumulate_grad_batches=1)
