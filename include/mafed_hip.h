@@ -37,7 +37,8 @@ enum {
 enum {
   MAFED_EPI_NONE = 0,
   MAFED_EPI_GELU = 1,     /* C = gelu_erf(acc + bias); aux (if non-NULL) receives the pre-activation acc + bias */
-  MAFED_EPI_GELU_BWD = 2  /* C = (acc) * gelu_erf'(aux) ; aux = saved pre-activation, same dtype as C */
+  MAFED_EPI_GELU_BWD = 2, /* C = (acc) * gelu_erf'(aux) ; aux = saved pre-activation, same dtype as C */
+  MAFED_EPI_RES1_BF16 = 0x100 /* flag, OR-ed in: res1 points at bf16 data (the attention branch output under bf16 autocast) */
 };
 
 int mafed_version(void);
@@ -48,7 +49,7 @@ const char* mafed_last_error_string(void);
  *   transA == 0: A stored [M,K] (lda >= K)     transA == 1: A stored [K,M] (lda >= M)
  *   transB == 0: B stored [K,N] (ldb >= N)     transB == 1: B stored [N,K] (ldb >= K)   (nn.Linear weight)
  * in_dtype MAFED_BF16: MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulate; MAFED_F32: exact fp32 FMA path (parity mode).
- * c_dtype may be F32 or BF16; res1/res2 are fp32 [M,N] (ld = ldc) or NULL; beta != 0 requires c_dtype F32.
+ * c_dtype may be F32 or BF16; res1/res2 are fp32 [M,N] (ld = ldc) or NULL (res1 may be bf16: MAFED_EPI_RES1_BF16); beta != 0 requires c_dtype F32.
  * Replaces: every nn.Linear on the path -- query_key_value / dense (tf:192-193,204,233), dense_h_to_4h /
  * dense_4h_to_h + GELU (tf:38-49), vision_embed_tokens (mafed/model/vl_pythia.py:226-234,270), embed_out (:213,310),
  * their autograd backward (dX = dY.W, dW += dY^T.X), and the parallel-residual add (tf:271-274) via res1/res2.

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmafed_hip.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+EPI_RES1_BF16 = 0x100
 
 _p, _i, _l, _f, _z, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 

@@ -792,13 +792,15 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
   MAFED_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm: N=%lld and ldc=%lld must be multiples of 4 (vector epilogue)",
                   (long long)N, (long long)ldc);
   MAFED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
+  const int res1_bf16 = (epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
+  epilogue &= ~MAFED_EPI_RES1_BF16;
   MAFED_CHECK_ARG(epilogue >= MAFED_EPI_NONE && epilogue <= MAFED_EPI_GELU_BWD, "gemm: unknown epilogue %d", epilogue);
   MAFED_CHECK_ARG(epilogue != MAFED_EPI_GELU_BWD || aux, "gemm: GELU_BWD epilogue needs aux");
   MAFED_CHECK_ARG(beta == 0.f || c_dtype == MAFED_F32, "gemm: beta != 0 requires an fp32 C");
   MAFED_CHECK_ARG((((uintptr_t)C | (uintptr_t)aux | (uintptr_t)res1 | (uintptr_t)res2 | (uintptr_t)bias) & 7) == 0,
                   "gemm: C/aux/res/bias must be at least 8-byte aligned");
   if (M == 0) return MAFED_OK;
-  GemmEpi epi{bias, epilogue, aux, res1, res2, beta, ldc};
+  GemmEpi epi{bias, epilogue, aux, res1, res2, res1_bf16, beta, ldc};
   hipStream_t st = as_stream(stream);
   if (in_dtype == MAFED_F32) {
     dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64)), block(256);
@@ -842,7 +844,7 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
   if (cfg == 0 && c_dtype == MAFED_F32 && beta == 1.0f && !bias && epilogue == MAFED_EPI_NONE && !res1 && !res2 && g_gemm_split != 1) {
     // weight-gradient GEMMs (dW += dY^T.X): few output tiles, very long K.  Split K so that the grid fills the chip.
     const int64_t tiles = (M / 128) * (N / 128), nkt = K / 64;
-    int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? 4 : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
+    int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? (nkt >= 512 ? 8 : 4) : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
     while (ns > 1 && nkt / ns < 8) ns >>= 1;
     g_gemm_nsplit = ns;
   }

@@ -8,8 +8,9 @@ struct GemmEpi {
   const float* bias;   // [N] or null
   int mode;            // MAFED_EPI_*
   void* aux;           // pre-activation [M,N] (ld = ldc), same dtype as C
-  const float* res1;   // fp32 [M,N] (ld = ldc) or null
-  const float* res2;
+  const float* res1;   // [M,N] (ld = ldc) or null; fp32, or bf16 when res1_bf16 is set
+  const float* res2;   // fp32 [M,N] or null
+  int res1_bf16;
   float beta;          // C = v + beta * C_old  (fp32 C only)
   int64_t ldc;
 };
@@ -32,7 +33,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmEpi& e, CT* __restrict
     else v = make_float4(v.x * gelu_erf_grad(u.x), v.y * gelu_erf_grad(u.y), v.z * gelu_erf_grad(u.z), v.w * gelu_erf_grad(u.w));
   }
   if (e.res1) {
-    const float4 r = load4(e.res1 + off);
+    const float4 r = e.res1_bf16 ? load4(reinterpret_cast<const bf16_t*>(e.res1) + off) : load4(e.res1 + off);
     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
   if (e.res2) {
@@ -93,7 +94,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
   }
   if (e.res1) {
     float r[8];
-    load8(e.res1 + off, r);
+    if (e.res1_bf16) load8(reinterpret_cast<const bf16_t*>(e.res1) + off, r);
+    else load8(e.res1 + off, r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += r[i];
   }

@@ -442,7 +442,8 @@ class VLPythiaForCausalLM(nn.Module):
                                                      cfg.layer_norm_eps, cd, save_stats=train)
             qkv = ops.gemm(ln1, w(pre + "attention.query_key_value.weight"), False, True, bias=self._p(pre + "attention.query_key_value.bias"))
             ao, lse = ops.attn_fwd(qkv, B, S, H, D, rot, cos, sin, attention_mask)
-            attn = ops.gemm(ao, w(pre + "attention.dense.weight"), False, True, bias=self._p(pre + "attention.dense.bias"), out_dtype=torch.float32)
+            # the attention branch output is a bf16 tensor under the reference's autocast too (it meets the fp32 residual in the add)
+            attn = ops.gemm(ao, w(pre + "attention.dense.weight"), False, True, bias=self._p(pre + "attention.dense.bias"), out_dtype=cd)
             u = torch.empty((rows, cfg.intermediate_size), dtype=cd, device=x.device) if train else None
             a = ops.gemm(ln2, w(pre + "mlp.dense_h_to_4h.weight"), False, True, bias=self._p(pre + "mlp.dense_h_to_4h.bias"), epilogue=EPI_GELU, aux=u)
             # h + attn(LN1(h)) + mlp(LN2(h)) in the last GEMM's epilogue (tf:271-274)
@@ -551,7 +552,12 @@ class VLPythiaForCausalLM(nn.Module):
             gl = dloss.reshape(1).to(torch.float32).contiguous()
             dlog = ops.ce_bwd(logits, sv["labels"], sv["ce_lse"], gl).view(B * T, cfg.vocab_size)
             wgrad(dlog, lnf, "embed_out.weight")
-            dlnf = ops.gemm(dlog, w("embed_out.weight"), False, False)
+            if cd == torch.bfloat16:
+                # [B*T, V] . [V, h]: 64 output tiles with K = 50304 -- accumulate-only fp32 output so that the GEMM splits K
+                dlnf = torch.zeros((B * T, h), dtype=torch.float32, device=dev)
+                ops.gemm(dlog, w("embed_out.weight"), False, False, out=dlnf, beta=1.0)
+            else:
+                dlnf = ops.gemm(dlog, w("embed_out.weight"), False, False)
             dxt, _ = ops.layernorm_bwd(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None,
                                        g("gpt_neox.final_layer_norm.weight"), g("gpt_neox.final_layer_norm.bias"))
             dx = torch.zeros((rows, h), dtype=torch.float32, device=dev)

@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from mafed_amd import _lib
-from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, F32, check  # noqa: F401
+from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_RES1_BF16, F32, check  # noqa: F401
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -88,6 +88,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
     assert out.shape == (M, N) and out.stride(1) == 1
+    if res1 is not None and res1.dtype == torch.bfloat16:
+        epilogue |= EPI_RES1_BF16
     prof = GEMM_EVENTS is not None and A.dtype == torch.bfloat16
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
