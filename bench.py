@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the step from a hipGraph (measured slower than eager launches on ROCm 7: 42.9 vs 39.7 ms)")
     ap.add_argument("--no-graphs", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
     args = ap.parse_args()
 
@@ -100,6 +101,9 @@ def main():
     from mafed_amd.methods import HBMReplayBuffer
     import torch.distributed as dist
 
+    if args.gemm_variant is not None:
+        from mafed_amd import _lib
+        _lib.load().mafed_gemm_set_variant(args.gemm_variant)
     rank, local, world = init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():

@@ -91,6 +91,7 @@ int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype,
                         float* dw1, float* db1, float* dw2, float* db2,
                         const float* teacher, const int64_t* attention_mask, int S, int P, int T,
                         const float* inj_scale_dev /* [2] device: {lang, vision} or NULL */, float inj_mul /* host factor, e.g. 2/h */,
+                        float* dxsum_a, float* dxsum_b /* optional fp32 [h]: += column sums of dx (bias grads of the layer below) */,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- attention (tf:154-236 eager path / flash-attn-2 wheel, README.md:16) ------------------------------------

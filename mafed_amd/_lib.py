@@ -27,7 +27,7 @@ SIGNATURES = {
     "mafed_colsum": (_i, [_p, _i, _l, _l, _l, _p, _p, _z, _p]),
     "mafed_layernorm_fwd": (_i, [_p, _l, _i, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
-    "mafed_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _p, _z, _p]),
+    "mafed_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _p, _p, _p, _z, _p]),
     "mafed_attn_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_attn_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_attn_set_variant": (_i, [_i]),

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // Backward.  Each block walks rows with stride gridDim.x*4; per-lane register partials of the four parameter
 // gradients are combined across the block's 4 waves through LDS and written to workspace [gridDim.x][4][h];
 // ln_param_reduce_kernel then sums the slabs deterministically and accumulates into dw/db.
-template <int NV, typename DyT, bool DUAL>
+// DXSUM: additionally accumulate the column sums of dx (= the bias gradients of the two Linear layers that produced the
+// residual branches of the layer below: both are sum_rows(dY) with dY = this dx), saving two column-sum passes per layer.
+template <int NV, typename DyT, bool DUAL, bool DXSUM>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restrict__ dy1, const DyT* __restrict__ dy2,
                                                             const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ w1,
@@ -69,13 +71,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
                                                             const float* __restrict__ inj_scale, float inj_mul,
                                                             float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [3 waves][NP][h] staging for the cross-wave sum
-  constexpr int NP = DUAL ? 4 : 2;
+  constexpr int NP = (DUAL ? 4 : 2) + (DXSUM ? 1 : 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 aw1[NV], ab1[NV], aw2[DUAL ? NV : 1], ab2[DUAL ? NV : 1];
+  float4 aw1[NV], ab1[NV], aw2[DUAL ? NV : 1], ab2[DUAL ? NV : 1], adx[DXSUM ? NV : 1];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     aw1[i] = ab1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (DUAL) aw2[i] = ab2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DXSUM) adx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float4 g1[NV], g2[DUAL ? NV : 1];
 #pragma unroll
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
         }
         store4(dx + row * h + c, o);
         if (dx_lp) store4(dx_lp + row * h + c, o);
+        if (DXSUM) { adx[i].x += o.x; adx[i].y += o.y; adx[i].z += o.z; adx[i].w += o.w; }
       }
     }
   }
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
         store4(stage + 0 * h + c, aw1[i]);
         store4(stage + 1 * h + c, ab1[i]);
         if (DUAL) { store4(stage + 2 * h + c, aw2[i]); store4(stage + 3 * h + c, ab2[i]); }
+        if (DXSUM) store4(stage + (NP - 1) * h + c, adx[i]);
       }
     }
   }
@@ -159,12 +164,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < h) {
-        float4 a = aw1[i], b = ab1[i], c2 = DUAL ? aw2[i] : a, d = DUAL ? ab2[i] : b;
+        float4 a = aw1[i], b = ab1[i], c2 = DUAL ? aw2[i] : a, d = DUAL ? ab2[i] : b, e = DXSUM ? adx[i] : a;
         for (int w = 0; w < 3; ++w) {
           const float* st = lds + (size_t)w * NP * h;
           float4 t0 = load4(st + 0 * h + c), t1 = load4(st + 1 * h + c);
           a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
           b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
+          if (DXSUM) {
+            float4 t4 = load4(st + (NP - 1) * h + c);
+            e.x += t4.x; e.y += t4.y; e.z += t4.z; e.w += t4.w;
+          }
           if (DUAL) {
             float4 t2 = load4(st + 2 * h + c), t3 = load4(st + 3 * h + c);
             c2.x += t2.x; c2.y += t2.y; c2.z += t2.z; c2.w += t2.w;
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
         store4(out + 0 * h + c, a);
         store4(out + 1 * h + c, b);
         if (DUAL) { store4(out + 2 * h + c, c2); store4(out + 3 * h + c, d); }
+        if (DXSUM) store4(out + (NP - 1) * h + c, e);
       }
     }
   }
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
 // out_k[c] += sum_b partial[b][k][c]   (k = 0..NP-1 -> dw1, db1, dw2, db2); 64 columns x 4 slab groups per block
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblk, int np, int h,
                                                               float* __restrict__ o0, float* __restrict__ o1,
-                                                              float* __restrict__ o2, float* __restrict__ o3) {
+                                                              float* __restrict__ o2, float* __restrict__ o3, int dxsum_slot,
+                                                              float* __restrict__ dxs_a, float* __restrict__ dxs_b) {
   __shared__ float sm[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + col;
@@ -205,8 +216,13 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   if (grp == 0 && idx < tot) {
     const float r = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
     const int k = idx / h, c = idx - k * h;
-    float* o = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
-    o[c] += r;
+    if (k == dxsum_slot) {
+      if (dxs_a) dxs_a[c] += r;
+      if (dxs_b) dxs_b[c] += r;
+    } else {
+      float* o = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+      o[c] += r;
+    }
   }
 }
 
@@ -260,14 +276,15 @@ extern "C" int mafed_layernorm_fwd(const float* x, int64_t rows, int h, float ep
 }
 
 extern "C" size_t mafed_layernorm_bwd_workspace_bytes(int64_t rows, int h) {
-  return (size_t)ln_bwd_blocks(rows) * 4 * (size_t)h * sizeof(float);
+  return (size_t)ln_bwd_blocks(rows) * 5 * (size_t)h * sizeof(float);
 }
 
 extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean,
                                    const float* rstd, const float* w1, const float* w2, int64_t rows, int h,
                                    const float* dres, float* dx, void* dx_lp, float* dw1, float* db1, float* dw2, float* db2,
                                    const float* teacher, const int64_t* attention_mask, int S, int P, int T,
-                                   const float* inj_scale_dev, float inj_mul, void* workspace, size_t workspace_bytes, void* stream) {
+                                   const float* inj_scale_dev, float inj_mul, float* dxsum_a, float* dxsum_b, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   MAFED_CHECK_ARG(dy1 && x && mean && rstd && w1 && dx && dw1 && db1, "layernorm_bwd: null pointer");
   MAFED_CHECK_ARG(h > 0 && h % 4 == 0, "layernorm_bwd: h=%d must be a positive multiple of 4", h);
   const bool dual = dy2 != nullptr;
@@ -278,7 +295,8 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
   MAFED_CHECK_ARG(nv > 0, "layernorm_bwd: h=%d > 2048 unsupported", h);
   if (rows == 0) return MAFED_OK;
   const int nblk = ln_bwd_blocks(rows);
-  const int np = dual ? 4 : 2;
+  const bool dxsum = dxsum_a != nullptr || dxsum_b != nullptr;
+  const int np = (dual ? 4 : 2) + (dxsum ? 1 : 0);
   if (workspace_bytes < (size_t)nblk * np * h * sizeof(float) || !workspace) {
     set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, (size_t)nblk * np * h * sizeof(float));
     return MAFED_EWORKSPACE;
@@ -288,17 +306,19 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
   hipStream_t st = as_stream(stream);
   float* partial = (float*)workspace;
   dim3 grid(nblk), block(256);
-#define LAUNCH(NV, T, DUAL)                                                                                              \
+#define LAUNCH(NV, T, DUAL, DXS)                                                                                         \
   do {                                                                                                                   \
-    auto kfn = layernorm_bwd_kernel<NV, T, DUAL>;                                                                        \
+    auto kfn = layernorm_bwd_kernel<NV, T, DUAL, DXS>;                                                                        \
     if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     kfn<<<grid, block, lds_bytes, st>>>((const T*)dy1, (const T*)dy2, x, mean, rstd, w1, w2, rows, h, dres, dx, (T*)dx_lp, \
                                         teacher, attention_mask, S, P, T_, inj_scale_dev, inj_mul, partial);                      \
   } while (0)
   const int T_ = T;
-#define DISPATCH_D(NV, TT) \
-  if (dual) LAUNCH(NV, TT, true); \
-  else LAUNCH(NV, TT, false)
+#define DISPATCH_D(NV, TT)                       \
+  if (dual && dxsum) LAUNCH(NV, TT, true, true);  \
+  else if (dual) LAUNCH(NV, TT, true, false);     \
+  else if (dxsum) LAUNCH(NV, TT, false, true);    \
+  else LAUNCH(NV, TT, false, false)
 #define DISPATCH_T(NV)                          \
   if (dy_dtype == MAFED_F32) { DISPATCH_D(NV, float); } \
   else { DISPATCH_D(NV, bf16_t); }
@@ -314,7 +334,8 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
 #undef LAUNCH
   MAFED_CHECK_LAUNCH("layernorm_bwd");
   const int tot = np * h;
-  ln_param_reduce_kernel<<<dim3((tot + 63) / 64), dim3(256), 0, st>>>(partial, nblk, np, h, dw1, db1, dw2, db2);
+  ln_param_reduce_kernel<<<dim3((tot + 63) / 64), dim3(256), 0, st>>>(partial, nblk, np, h, dw1, db1, dw2, db2, dxsum ? np - 1 : -1,
+                                                                      dxsum_a, dxsum_b);
   MAFED_CHECK_LAUNCH("layernorm_bwd(param reduce)");
   return MAFED_OK;
 }

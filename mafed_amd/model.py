@@ -564,10 +564,15 @@ class VLPythiaForCausalLM(nn.Module):
             dx.view(B, S, h)[:, P:, :] = dxt.view(B, T, h)
             ready(L)
         dy = None  # dx in compute dtype (GEMM operand)
+        dy_bias_done = False  # colsum(dy) already accumulated into this layer's two residual-branch bias gradients
         for i in range(L - 1, -1, -1):
             ext = dhidden[i + 1] if (i + 1) < min(len(dhidden), L) else None  # grad of hidden_states[i+1] = output of layer i
             if ext is not None:
                 ext = ext.reshape(rows, h)
+                if dx is not None and dy_bias_done:
+                    # the LayerNorm backward above already added colsum(dx) to this layer's bias gradients: add the rest
+                    ops.colsum_(ext.to(torch.float32).contiguous(), g(f"gpt_neox.layers.{i}.mlp.dense_4h_to_h.bias"))
+                    ops.colsum_(ext.to(torch.float32).contiguous(), g(f"gpt_neox.layers.{i}.attention.dense.bias"))
                 dx = ext.to(torch.float32) if dx is None else dx.add_(ext)
                 dy = None
             inj = inject.get(i) if inject else None
@@ -582,8 +587,8 @@ class VLPythiaForCausalLM(nn.Module):
             pre = f"gpt_neox.layers.{i}."
             s = sv["layers"][i]
             # parameter gradients that only need dy: MLP down-projection and attention output projection
-            wgrad(dy, s["a"], pre + "mlp.dense_4h_to_h.weight", pre + "mlp.dense_4h_to_h.bias")
-            wgrad(dy, s["ao"], pre + "attention.dense.weight", pre + "attention.dense.bias")
+            wgrad(dy, s["a"], pre + "mlp.dense_4h_to_h.weight", None if dy_bias_done else pre + "mlp.dense_4h_to_h.bias")
+            wgrad(dy, s["ao"], pre + "attention.dense.weight", None if dy_bias_done else pre + "attention.dense.bias")
             # MLP branch
             du = ops.gemm(dy, w(pre + "mlp.dense_4h_to_h.weight"), False, False, epilogue=EPI_GELU_BWD, aux=s["u"])
             wgrad(du, s["ln2"], pre + "mlp.dense_h_to_4h.weight", pre + "mlp.dense_h_to_4h.bias")
@@ -600,7 +605,10 @@ class VLPythiaForCausalLM(nn.Module):
                                        g(pre + "post_attention_layernorm.weight"), g(pre + "post_attention_layernorm.bias"),
                                        want_lp=(cd != torch.float32),
                                        teacher=inj[0].view(rows, h) if inj is not None else None, attention_mask=am if inj is not None else None,
-                                       S=S, P=P, inj_scale=inj[1] if inj is not None else None, inj_mul=2.0 / h)
+                                       S=S, P=P, inj_scale=inj[1] if inj is not None else None, inj_mul=2.0 / h,
+                                       dxsum_a=g(f"gpt_neox.layers.{i - 1}.mlp.dense_4h_to_h.bias") if i > 0 else None,
+                                       dxsum_b=g(f"gpt_neox.layers.{i - 1}.attention.dense.bias") if i > 0 else None)
+            dy_bias_done = i > 0
             if cd == torch.float32:
                 dy = dx
             if taps is not None and i in taps:

@@ -124,7 +124,8 @@ def layernorm_fwd(x: torch.Tensor, w1, b1, w2=None, b2=None, eps: float = 1e-5, 
 
 
 def layernorm_bwd(dy1, dy2, x, mean, rstd, w1, w2, dres, dw1, db1, dw2=None, db2=None, want_lp: bool = False,
-                  teacher=None, attention_mask=None, S: int = 0, P: int = 0, inj_scale=None, inj_mul: float = 1.0):
+                  teacher=None, attention_mask=None, S: int = 0, P: int = 0, inj_scale=None, inj_mul: float = 1.0,
+                  dxsum_a=None, dxsum_b=None):
     rows, h = x.shape
     dx = torch.empty((rows, h), dtype=torch.float32, device=x.device)
     dx_lp = torch.empty((rows, h), dtype=dy1.dtype, device=x.device) if want_lp else None
@@ -133,7 +134,8 @@ def layernorm_bwd(dy1, dy2, x, mean, rstd, w1, w2, dres, dw1, db1, dw2=None, db2
     ws = workspace(x.device).get(nb)
     check(lib.mafed_layernorm_bwd(_ptr(dy1), _ptr(dy2), _dt(dy1), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w1), _ptr(w2), rows, h,
                                   _ptr(dres), _ptr(dx), _ptr(dx_lp), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(teacher),
-                                  _ptr(attention_mask), S, P, S - P, _ptr(inj_scale), float(inj_mul), _ptr(ws), ws.numel(), _stream()),
+                                  _ptr(attention_mask), S, P, S - P, _ptr(inj_scale), float(inj_mul), _ptr(dxsum_a), _ptr(dxsum_b), _ptr(ws), ws.numel(),
+                                  _stream()),
           "mafed_layernorm_bwd")
     return dx, dx_lp
 
