@@ -81,8 +81,8 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="410m")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img-tokens", type=int, default=256)
@@ -198,8 +198,14 @@ def main():
             ms = sum(a.elapsed_time(b) for a, b, _ in ev)
             fl = sum(f for _, _, f in ev)
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            try:  # HBM-side bytes per launch of this kernel from the committed PMC run (FETCH_SIZE x2-corrected + WRITE_SIZE)
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
+                    traffic = json.load(fp)["hbm_MB_per_launch"] * 1e6
+            except Exception:
+                pass
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch of 2 eagerly launched steps after the timed region)",
+                    "traffic": traffic, "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch of 2 more steps run right after the timed region)",
                     "launches": len(ev), "avg_launch_us": round(ms * 1e3 / len(ev), 2), "avg_gflop_per_launch": round(fl / len(ev) / 1e9, 3),
                     "note": "launch durations overlap: dW GEMMs and the teacher forward run on side streams"}
         out = {"metric": "train samples/sec VLPythia-410M+MAFED, 256img+32txt tok, bs=32, 1/2/4/8 GPU" if args.model == "410m" else

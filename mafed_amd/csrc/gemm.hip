@@ -399,6 +399,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       epilogue_store8<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v);
     }
+  } else if constexpr (MT == 6 && NT == 4 && STAGE * 2 >= NW * 12288) {
+    // 96 x 64 wave tile (192 x 128 block): two passes of 3 row tiles through a wave-private 48 x 64 fp32 region
+    __syncthreads();
+    float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int row = t * 16 + (lane & 15);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int c4 = (nt * 4 + (lane >> 4)) ^ (row & 15);
+          *reinterpret_cast<f32x4*>(reg + row * 64 + c4 * 4) = acc[nt][pass * 3 + t];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int row = it * 8 + (lane >> 3), j = lane & 7;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        epilogue_store8<CT>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   } else if constexpr (MT == 9 && NT == 4 && STAGE * 2 >= NW * 12288) {
     // 144 x 64 wave tile (288 x 256 block): three passes of 3 row tiles through a wave-private 48 x 64 fp32 region
     __syncthreads();
@@ -764,6 +790,7 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
     case 12: if constexpr (!A_KS) return launch_bf16_glds<3, 2, 3, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 6 waves of 48x64
     case 13: if constexpr (!A_KS) return launch_bf16_glds<1, 8, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x256, 8 waves of 144x32
     case 16: if constexpr (!A_KS) return launch_bf16_glds<2, 4, 9, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 288x256, 8 waves of 144x64 (136 KiB, 1 block / CU)
+    case 17: if constexpr (!A_KS) return launch_bf16_glds<2, 2, 6, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 192x128, 4 waves of 96x64 (80 KiB: 2 blocks / CU)
     case 14: return launch_bf16_glds<2, 2, 4, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x64, 4 waves of 64x32 (48 KiB: 3 blocks / CU)
     case 15: return launch_bf16_glds<2, 2, 2, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 64x128
     case 21: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 1>(M, N, K, A, lda, B, ldb, C, epi, st);  // ablations (timing only)
@@ -855,6 +882,7 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
       const bool ok144 = (M % 144 == 0) && (N % 128 == 0) && !a_ks, ok144x256 = (M % 144 == 0) && (N % 256 == 0) && !a_ks;
       if (((want == 11 || want == 12) && ok144) || (want == 13 && ok144x256)) cfg = want;
       else if (want == 16 && (M % 288 == 0) && (N % 256 == 0) && !a_ks) cfg = 16;
+      else if (want == 17 && (M % 192 == 0) && (N % 128 == 0) && !a_ks) cfg = 17;
       else if (want == 14 && (M % 128 == 0) && (N % 64 == 0)) cfg = 14;
       else if (want == 15 && (M % 64 == 0) && (N % 128 == 0)) cfg = 15;
       else if (((want == 0 || want == 3 || want == 6 || want == 7 || want == 9 || want == 10 || (want >= 21 && want <= 26)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
@@ -867,6 +895,9 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
         auto eff = [](int64_t t) { return (double)t / (double)(((t + 511) / 512) * 512); };
         const double e144 = eff((M / 144) * (N / 128)), e128 = ok128 ? eff((M / 128) * (N / 128)) : 0.0;
         if (e144 >= e128) cfg = 11;
+        // 192 x 128 tiles (96 x 64 per wave: 31 % fewer LDS fragment reads and 22 % fewer DMA pieces per MFMA, still two
+        // blocks per CU) when they fill the 512 slots in whole rounds: the N = 4096 GEMMs (1536 tiles); 895-917 vs 840-856
+        if ((M % 192 == 0) && (((M / 192) * (N / 128)) % 512 == 0)) cfg = 17;
         // 288 x 256 tiles (one 8-wave block per CU, half the DMA and 28 % fewer LDS reads per MFMA) when they fill the
         // 256 CUs in whole rounds: the N = 4096 GEMMs of the step (512 tiles); measured 944-958 vs 846-849 TFLOP/s
         if ((M % 288 == 0) && (N % 256 == 0) && (((M / 288) * (N / 256)) % 256 == 0) && g_gemm_big) cfg = 16;  // measured >= the 128-row tile on every M = 9216 shape once both use the LDS-staged epilogue

@@ -202,7 +202,14 @@ class FeatureDistillation(CLStrategy):
         layers = self.loss_weights.get_distillation_layers()
         main = torch.cuda.current_stream()
         side = pm.side_stream()
-        side.wait_stream(main)  # everything of the previous step (which may still read last step's teacher states) is ordered first
+        # Order behind the previous step's backward (the last reader of the previous teacher states, whose memory this
+        # forward re-uses) -- NOT behind its optimiser: the frozen teacher does not depend on the update, so its forward
+        # overlaps the HBM-bound clip + AdamW tail of the previous step.
+        ev_prev = getattr(self, "backward_done_event", None)
+        if ev_prev is not None:
+            side.wait_event(ev_prev)
+        else:
+            side.wait_stream(main)
         kw = {"patch_embeddings": batch["patch_embeddings"]} if "patch_embeddings" in batch else {"pixel_values": batch["pixel_values"]}
         with torch.cuda.stream(side):
             hs = [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=max(layers) + 1, **kw)]

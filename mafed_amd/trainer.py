@@ -120,6 +120,9 @@ class Trainer:
             self.reducer.enabled = window_end  # all-reduce only on the last micro-batch of an accumulation window
         loss, branch = self._training_step(batch, is_replay)
         (loss / self.accumulate if self.accumulate != 1 else loss).backward()
+        if torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
+            # lets the next step's frozen-teacher forward start here, under this step's clip + AdamW
+            self.cl_method.backward_done_event = torch.cuda.current_stream().record_event()
         rec: Dict[str, Any] = {"loss": loss.detach(), "branch": branch, "stepped": False}
         if window_end:
             self.cl_method.update_after_backward(model=self.model)  # on_before_optimizer_step

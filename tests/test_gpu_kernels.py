@@ -56,9 +56,9 @@ def _int_mat(shape, g, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27])
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320), (288, 512, 192), (576, 384, 128), (576, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320), (288, 512, 192), (576, 384, 128), (576, 768, 256), (384, 256, 128)])
 def test_gemm_bf16_exact_integers(tA, tB, M, N, K, variant):
     """Small-integer operands are exact in bf16 and the fp32 accumulator: any wrong fragment / transposing-read /
     swizzle mapping shows up as a hard mismatch (asymmetric data)."""
