@@ -9,7 +9,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmafed_hip.so")
+LIB_PATH = os.environ.get("MAFED_HIP_LIB") or os.path.join(_HERE, "libmafed_hip.so")  # override: A/B of two builds
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2

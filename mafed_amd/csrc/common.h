@@ -112,29 +112,44 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-// Fast erf-GELU for the bf16 MFMA epilogues (Abramowitz-Stegun 7.1.26, |err(erf)| <= 1.5e-7; one v_exp + one v_rcp):
-// the libm erff costs more VALU time than the MFMA main loop leaves idle.  exp(-z^2) with z = x/sqrt(2) is also the
-// Gaussian of gelu', so the derivative needs no second exponential.  The fp32 parity path keeps erff.
-__device__ __forceinline__ void erf_gauss_fast(float x, float& erf_z, float& gauss) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  gauss = __expf(-z * z);  // = exp(-x^2 / 2)
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * gauss;
-  erf_z = copysignf(e, x);
+// Fast erf-GELU for the bf16 MFMA epilogues (Abramowitz-Stegun 7.1.26, |err(erf)| <= 1.5e-7; one v_exp + one v_rcp per
+// element): the libm erff costs more VALU time than the MFMA main loop leaves idle.  exp(-z^2) with z = x/sqrt(2) is also
+// the Gaussian of gelu', so the derivative needs no second exponential.  Written on float2 so that the polynomial, the
+// scalings and the final combination compile to packed v_pk_{mul,add,fma}_f32 (two elements per instruction); only the
+// two transcendentals and the sign handling stay per element.  The fp32 parity path keeps erff.
+__device__ __forceinline__ void erf_gauss_fast2(f32x2 x, f32x2& erf_z, f32x2& gauss) {
+  f32x2 ax;
+  ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 den = z * 0.3275911f + 1.0f;
+  f32x2 t;
+  t[0] = __frcp_rn(den[0]); t[1] = __frcp_rn(den[1]);
+  const f32x2 a = z * z * -1.4426950408889634f;  // exp(-z^2) = exp2(-z^2 * log2 e)
+  gauss[0] = __builtin_amdgcn_exp2f(a[0]); gauss[1] = __builtin_amdgcn_exp2f(a[1]);
+  f32x2 p = t * 1.061405429f + -1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t + -0.284496736f;
+  p = p * t + 0.254829592f;
+  const f32x2 e = 1.0f - p * t * gauss;
+  erf_z[0] = copysignf(e[0], x[0]); erf_z[1] = copysignf(e[1], x[1]);
+}
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+  f32x2 e, g;
+  erf_gauss_fast2(x, e, g);
+  return x * 0.5f * (e + 1.0f);
+}
+__device__ __forceinline__ f32x2 gelu_erf_grad_fast2(f32x2 x) {
+  f32x2 e, g;
+  erf_gauss_fast2(x, e, g);
+  return (e + 1.0f) * 0.5f + x * 0.39894228040143267794f * g;
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  float e, g;
-  erf_gauss_fast(x, e, g);
-  return 0.5f * x * (1.0f + e);
+  f32x2 v = {x, x};
+  return gelu_erf_fast2(v)[0];
 }
 __device__ __forceinline__ float gelu_erf_grad_fast(float x) {
-  float e, g;
-  erf_gauss_fast(x, e, g);
-  return 0.5f * (1.0f + e) + x * 0.39894228040143267794f * g;
+  f32x2 v = {x, x};
+  return gelu_erf_grad_fast2(v)[0];
 }
 
 // modality class of a token row (mafed/methods/distillation.py:134-144): 0 = language (valid text), 1 = vision, 2 = none (pad)

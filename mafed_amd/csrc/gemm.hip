@@ -283,7 +283,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int64_t m0 = (int64_t)(bid / tiles_n) * TM, n0 = (int64_t)(bid % tiles_n) * TN;
+  // grouped tile order inside the XCD's run: GROUP_M row-tiles x all column tiles, walked column-major, so that the ~64
+  // blocks resident on one XCD form an ~8 x 8 patch (8 A panels + 8 B panels per K-step through its 4 MiB L2) instead of
+  // a 2 x 32 strip (2 + 32 panels): FETCH_SIZE showed the weight operand re-read ~24x per GEMM with the strip order
+  int tile_m, tile_n;
+  {
+    const int GROUP_M = tiles_n >> 20;
+    const int tiles_n_ = tiles_n & 0xfffff;
+    const int tiles_m = nwg / tiles_n_, gsz = GROUP_M * tiles_n_;
+    const int group = bid / gsz, first_m = group * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int within = bid - group * gsz;
+    tile_m = first_m + within % gm;
+    tile_n = within / gm;
+  }
+  const int64_t m0 = (int64_t)tile_m * TM, n0 = (int64_t)tile_n * TN;
 
   // per-lane DMA sources (piece j = wave + i * NW); k-tile advance is +64 elements (KC) or +64 rows (KS)
   const bf16_t* asrc[A_PER_WAVE];
@@ -495,6 +509,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   }
 }
 
+static int g_gemm_group_m = 4;  // row-tiles per L2 patch of the grouped tile order (tuning: variant 300 + g)
 static int g_gemm_nsplit = 1;  // set by the dispatcher for the next launch_bf16_glds<2,2,4,4,...> (split-K, accumulate-only)
 
 template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0>
@@ -511,7 +526,7 @@ static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int6
   }
   const int nsplit = (MT == 4 && NT == 4 && WM == 2 && WN == 2) ? g_gemm_nsplit : 1;
   kfn<<<dim3((unsigned)nwg, (unsigned)nsplit), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi,
-                                                                               (int)tn, (int)nwg);
+                                                                               (int)tn | (g_gemm_group_m << 20), (int)nwg);
   return MAFED_OK;
 }
 
@@ -834,6 +849,7 @@ static int g_gemm_variant = 0;
 static int g_gemm_big = 0;    // 288x256 configuration in automatic mode (200 = off, 201 = on): faster alone, slower beside the side streams
 static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
 extern "C" int mafed_gemm_set_variant(int v) {
+  if (v >= 300) { g_gemm_group_m = v - 300 > 0 ? v - 300 : 1; return MAFED_OK; }
   if (v >= 200) { g_gemm_big = v - 200; return MAFED_OK; }
   if (v >= 100) { g_gemm_split = v - 100; return MAFED_OK; }  // 100 = automatic split-K, 101 = off, 100 + n = force n
   g_gemm_variant = v;

@@ -85,12 +85,18 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
   if (e.mode == MAFED_EPI_GELU) {
     if (e.aux) store8(reinterpret_cast<CT*>(e.aux) + off, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_erf_fast(v[i]);
+    for (int i = 0; i < 8; i += 2) {
+      const f32x2 r = gelu_erf_fast2((f32x2){v[i], v[i + 1]});
+      v[i] = r[0]; v[i + 1] = r[1];
+    }
   } else if (e.mode == MAFED_EPI_GELU_BWD) {
     float u[8];
     load8(reinterpret_cast<const CT*>(e.aux) + off, u);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= gelu_erf_grad_fast(u[i]);
+    for (int i = 0; i < 8; i += 2) {
+      const f32x2 r = gelu_erf_grad_fast2((f32x2){u[i], u[i + 1]});
+      v[i] *= r[0]; v[i + 1] *= r[1];
+    }
   }
   if (e.res1) {
     float r[8];

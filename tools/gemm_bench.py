@@ -24,6 +24,7 @@ SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
     ("dlnf  NN", False, False, 1024, 1024, 50304, torch.bfloat16),
     ("proj  NT", False, True, 8192, 1024, 1024, torch.bfloat16),
 ]
+EPI = os.environ.get("GEMM_BENCH_EPI", "0") == "1"   # fc1 with bias + GELU + saved pre-activation, dfc2 with GELU'
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
 lib = _lib.load()
 g = torch.Generator(device=dev).manual_seed(0)
@@ -34,10 +35,17 @@ for name, tA, tB, m, n, k, od in SHAPES:
     out = torch.zeros((m, n), dtype=od, device=dev)
     ref = None
     beta = 1.0 if (tA and od == torch.float32) else 0.0   # weight-gradient GEMMs accumulate into the gradient buffer
+    kw = {}
+    if EPI and name.startswith("fc1"):
+        kw = dict(bias=torch.randn(n, device=dev), epilogue=ops.EPI_GELU, aux=torch.empty((m, n), dtype=od, device=dev))
+    elif EPI and name.startswith("dfc2"):
+        kw = dict(epilogue=ops.EPI_GELU_BWD, aux=torch.randn((m, n), device=dev).to(od))
+    elif EPI and name.startswith("fc2"):
+        kw = dict(bias=torch.randn(n, device=dev), res1=torch.randn((m, n), device=dev).to(torch.bfloat16), res2=torch.randn((m, n), device=dev))
     for v in variants:
         lib.mafed_gemm_set_variant(v)
         out.zero_()
-        ops.gemm(A, B, tA, tB, out=out, beta=beta)
+        ops.gemm(A, B, tA, tB, out=out, beta=beta, **kw)
         if ref is None:
             ref = out.float().clone()
         elif v < 30 or v >= 100:
@@ -50,7 +58,7 @@ for name, tA, tB, m, n, k, od in SHAPES:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                ops.gemm(A, B, tA, tB, out=out, beta=beta)
+                ops.gemm(A, B, tA, tB, out=out, beta=beta, **kw)
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 10)
