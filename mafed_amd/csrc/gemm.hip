@@ -15,6 +15,10 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+#ifndef MAFED_GEMM_SPREAD_DMA
+#define MAFED_GEMM_SPREAD_DMA 0  // measured: spreading the DMA pieces between MFMA rows is 1.6x SLOWER (fc1 112 -> 180 us) -- the burst stays
+#endif
+
 namespace mafed {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -320,6 +324,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       if (NB % NW == 0 || wave + i * NW < NB)
         __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + kt * b_step), (lds_void_ptr)(sb + (wave + i * NW) * 1024), 16, 0, 0);
   };
+  // one DMA piece (compile-time index p over this wave's A then B pieces): lets the main loop spread the pieces between
+  // MFMA groups instead of issuing them as one burst (a piece costs ~60 issue cycles among MFMAs, 100-185 in a burst)
+  auto issue_piece = [&](int stage, int kt, int p) {
+    char* sa = smem + stage * STAGE;
+    char* sb = sa + A_BYTES;
+    if (p < A_PER_WAVE) {
+      if (NA % NW == 0 || wave + p * NW < NA)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[p] + kt * a_step), (lds_void_ptr)(sa + (wave + p * NW) * 1024), 16, 0, 0);
+    } else {
+      const int q = p - A_PER_WAVE;
+      if (NB % NW == 0 || wave + q * NW < NB)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[q] + kt * b_step), (lds_void_ptr)(sb + (wave + q * NW) * 1024), 16, 0, 0);
+    }
+  };
+  constexpr int NPIECE = A_PER_WAVE + B_PER_WAVE;
+  constexpr bool SPREAD = MAFED_GEMM_SPREAD_DMA && ABL == 0 && NPIECE <= 2 * MT;
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -338,7 +358,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     if (ABL != 6) __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
-    if (ABL != 1 && ABL != 5 && ABL != 6 && kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+    const bool more = kt + 1 < nkt;
+    if (!SPREAD && ABL != 1 && ABL != 5 && ABL != 6 && more) issue((kt + 1) & 1, kt + 1);
     const char* sa = smem + (kt & 1) * STAGE;
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -362,10 +383,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
         for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(fa[t]));
       } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+          if (SPREAD) {
+            const int p = ks * MT + mt;  // one piece after each row of MFMAs until this wave's pieces are out
+            if (p < NPIECE && more) issue_piece((kt + 1) & 1, kt + 1, p);
+          }
+        }
       }
     }
   }
