@@ -215,6 +215,9 @@ __device__ __forceinline__ void store_grad_unrot(bf16_t* __restrict__ rowp, f32x
 }
 
 __device__ __forceinline__ bool key_ok(const int64_t* __restrict__ am, int b, int key, int P, int T, int S) {
+#if defined(MAFED_ATTN_ABL) && MAFED_ATTN_ABL == 2
+  return key < S;
+#endif
   return key < P || (key < S && am[(int64_t)b * T + (key - P)] != 0);
 }
 
@@ -486,72 +489,155 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
 // ------------------------------------------------------------------------------------------------------------
 // "Resident" kernels for short sequences (S = 288 on the MAFED path): ONE block per (batch, head) stages the whole K and
 // V (or Q and dO for dK/dV) of that head into LDS once -- 288 x 64 x 2 B x 2 = 72 KiB at D = 64, two blocks per CU --
-// and its four waves walk the 16-row slices in a zig-zag order that balances the causal work.  No per-tile re-staging
-// (the tiled kernels above re-read K/V 3.2x at S = 288 and pay two barriers per 64 keys), no barrier after the first.
-// The tiled kernels remain the path for sequences whose K/V do not fit.
+// and its four waves walk the 16-row slices heaviest first in a boustrophedon order that balances the causal work.
+//  * staging is LDS-DMA (global_load_lds_dwordx4, swizzle applied to the source address): every piece of both matrices is
+//    in flight at once and no VGPR is touched; the partial rotary is then applied in place on the 2*rot/16 chunks it covers
+//  * the key-padding mask becomes an additive 0 / -inf row in LDS, the causal test a compare + select: no branches and no
+//    global loads inside the tile loop (the branchy form cost more than the MFMAs); the 16-key sub-tiles of the diagonal
+//    tile that lie entirely above the diagonal are skipped
+//  * softmax in the exp2 domain (scale * log2 e folded into one multiply; v_exp_f32 is exp2)
+//  * the four-lane column reductions use the gfx950 v_permlane{16,32}_swap instead of ds_bpermute
+// The tiled kernels above remain the path for sequences whose K/V do not fit.
 // ------------------------------------------------------------------------------------------------------------
-template <int D, bool ROT>
-__device__ __forceinline__ void stage_all_rows(char* __restrict__ img, const bf16_t* __restrict__ base, int64_t rstride, int nrows_pad, int S,
-                                               int rot, const float* __restrict__ rc, const float* __restrict__ rs, int tid) {
-  // batches of U chunks per thread: all global loads of a batch are issued before the first LDS write, so the HBM/L2
-  // latency is paid once per batch instead of once per 16 bytes (a runtime-bounded loop is not pipelined by hipcc)
-  constexpr int CPR = D / 8, U = 6;
-  const int total = nrows_pad * CPR;
-  for (int c0 = tid; c0 < total; c0 += 256 * U) {
-    uint4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int c = c0 + 256 * u;
-      const int row = c / CPR, ch = c % CPR;
-      if (c < total) {
-        if (ROT) v[u] = load_chunk_rot(base + (int64_t)row * rstride, ch, rot, rc, rs, row, row < S);
-        else v[u] = row < S ? *reinterpret_cast<const uint4*>(base + (int64_t)row * rstride + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
-      }
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float col_max_sw(float v) {
+  u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float col_sum_sw(float v) {
+  u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// DMA `nrows` rows (multiple of 32) of a [*, D] matrix into the swizzled image; rows >= S re-read row S-1 (finite data that
+// the masks turn into exact zeros).  1 KiB per wave instruction = 8 rows (D = 64) or 4 rows (D = 128).
+template <int D>
+__device__ __forceinline__ void dma_rows(char* __restrict__ img, const bf16_t* __restrict__ base, int64_t rstride, int nrows, int S, int wave,
+                                         int lane) {
+  constexpr int RPP = 1024 / (2 * D);
+  const int npieces = nrows / RPP;
+  for (int j = wave; j < npieces; j += 4) {
+    int row, logical;
+    if (D == 64) {
+      row = j * 8 + (lane >> 3);
+      logical = (lane & 7) ^ ((row >> 1) & 7);
+    } else {
+      row = j * 4 + (lane >> 4);
+      logical = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int c = c0 + 256 * u;
-      if (c < total) *reinterpret_cast<uint4*>(img + tile_off<D>(c / CPR, c % CPR)) = v[u];
-    }
+    const int srow = row < S ? row : S - 1;
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)(base + (int64_t)srow * rstride + logical * 8), (lds_void_ptr)(img + j * 1024), 16, 0, 0);
   }
 }
 
-// slice order of wave w: w, 7-w, 8+w, 15-w, 16+w, ...  (16-row slices; causal cost grows with the slice index)
-__device__ __forceinline__ int zigzag_slice(int w, int t) { return (t >> 1) * 8 + ((t & 1) ? 7 - w : w); }
+// In-place partial rotary (tf:111-151) of the staged rows: item = (row, chunk c of the first rotary half); the cos / sin
+// rows of a thread's first two items are fetched before the DMA wait.
+struct RotPre {
+  float4 c0, c1, s0, s1;
+};
+__device__ __forceinline__ void rot_pre_load(RotPre& r, int it, int hc, int rot, const float* __restrict__ rc, const float* __restrict__ rs) {
+  const int row = it / hc, c = it - row * hc;
+  const float* cp = rc + (int64_t)row * (rot >> 1) + c * 8;
+  const float* sp = rs + (int64_t)row * (rot >> 1) + c * 8;
+  r.c0 = load4(cp); r.c1 = load4(cp + 4); r.s0 = load4(sp); r.s1 = load4(sp + 4);
+}
+template <int D>
+__device__ __forceinline__ void rot_apply(char* __restrict__ img, int it, int hc, const RotPre& r) {
+  const int row = it / hc, c = it - row * hc;
+  uint4* p1 = reinterpret_cast<uint4*>(img + tile_off<D>(row, c));
+  uint4* p2 = reinterpret_cast<uint4*>(img + tile_off<D>(row, c + hc));
+  float x1[8], x2[8], o1[8], o2[8];
+  unpack8(*p1, x1);
+  unpack8(*p2, x2);
+  const float cs[8] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w, r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+  const float sn[8] = {r.s0.x, r.s0.y, r.s0.z, r.s0.w, r.s1.x, r.s1.y, r.s1.z, r.s1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+    o2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+  }
+  *p1 = pack8(o1);
+  *p2 = pack8(o2);
+}
+template <int D>
+__device__ __forceinline__ void rot_fix_rows(char* __restrict__ img, int items, int hc, int rot, const float* __restrict__ rc,
+                                             const float* __restrict__ rs, const RotPre (&pre)[2], int tid) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + 256 * u < items) rot_apply<D>(img, tid + 256 * u, hc, pre[u]);
+  for (int it = tid + 512; it < items; it += 256) {
+    RotPre r;
+    rot_pre_load(r, it, hc, rot, rc, rs);
+    rot_apply<D>(img, it, hc, r);
+  }
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// slice of wave w in round t: rounds of 4 slices, direction alternating, from the heaviest slice down
+__device__ __forceinline__ int snake4(int w, int t) { return t * 4 + ((t & 1) ? 3 - w : w); }
+
+#define MAFED_LOG2E 1.4426950408889634f
+#define MAFED_LN2 0.6931471805599453f
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
                                                            const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int spad = (S + 63) / 64 * 64;
+  const int nrows = (S + 31) / 32 * 32;
   char* kimg = lds;
-  char* vimg = lds + spad * D * 2;
+  char* vimg = lds + nrows * D * 2;
+  float* kbias = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
   const int64_t rstride = (int64_t)H * 3 * D;
   const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
   const bf16_t* kb = qb + D;
   const bf16_t* vb = qb + 2 * D;
-  stage_all_rows<D, true>(kimg, kb, rstride, spad, S, rot, rc, rs, tid);
-  stage_all_rows<D, false>(vimg, vb, rstride, spad, S, rot, rc, rs, tid);
-  __syncthreads();
-  const int g = lane >> 4;
-  const float scale = rsqrtf((float)D);
   const int nslices = (S + 15) / 16;
+  const int hc = rot >> 4, items = S * hc;
+  dma_rows<D>(kimg, kb, rstride, nrows, S, wave, lane);
+  dma_rows<D>(vimg, vb, rstride, nrows, S, wave, lane);
+  RotPre pre[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + 256 * u < items) rot_pre_load(pre[u], tid + 256 * u, hc, rot, rc, rs);
+  for (int k = tid; k < nrows; k += 256) kbias[k] = key_ok(am, b, k, P, T, S) ? 0.f : -INFINITY;
   ColRaw<D> qraw;
-  col_raw_issue<D, true>(qraw, qb, rstride, zigzag_slice(wave, 0) * 16, S, rot, rc, rs, lane);  // slice 0..3 always exists... or is all-zero
+  {
+    const int s0 = nslices - 1 - snake4(wave, 0);
+    if (s0 >= 0) col_raw_issue<D, true>(qraw, qb, rstride, s0 * 16, S, rot, rc, rs, lane);
+  }
+  wait_vm0();
+  __syncthreads();
+  rot_fix_rows<D>(kimg, items, hc, rot, rc, rs, pre, tid);
+  __syncthreads();
+#if defined(MAFED_ATTN_ABL) && MAFED_ATTN_ABL == 1
+  if (tid < 64) out[((int64_t)b * S + tid) * H * D + (int64_t)h * D] = *reinterpret_cast<const bf16_t*>(kimg + tid * 1024) + *reinterpret_cast<const bf16_t*>(vimg + tid * 1024);
+  return;
+#endif
+  const int g = lane >> 4;
+  const float scale2 = rsqrtf((float)D) * MAFED_LOG2E;
   for (int t = 0;; ++t) {
-    const int slice = zigzag_slice(wave, t);
-    if (slice >= nslices) break;  // zig-zag order is increasing per wave except inside a pair; a pair's later member is checked below
+    const int slice = nslices - 1 - snake4(wave, t);
+    if (slice < 0) break;
     const int q0 = slice * 16;
     const int myq = q0 + (lane & 15);
     bf16x8 qf[D / 32];
     col_raw_finish<D, true>(qf, qraw, q0, S, rot, lane);
     {
-      const int nxt = zigzag_slice(wave, t + 1);
-      if (nxt < nslices) col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
+      const int nxt = nslices - 1 - snake4(wave, t + 1);
+      if (nxt >= 0) col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
     }
     f32x4 o[D / 16];
 #pragma unroll
@@ -559,59 +645,81 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restr
     float m = -INFINITY, l = 0.f;
     const int last_kt = (q0 + 15) / 64;
     for (int kt = 0; kt <= last_kt; ++kt) {
+      const int nj = kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4;  // 16-key sub-tiles with a key <= q0 + 15
       f32x4 s[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < nj) {
 #pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks)
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s[j], 0, 0, 0);
+          for (int ks = 0; ks < D / 32; ++ks)
+            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s[j], 0, 0, 0);
+        }
       }
       const bool need_mask = (kt == last_kt) || (kt * 64 + 63 >= P);
       float tmax = -INFINITY;
+      if (need_mask) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+          if (j < nj) {
+            const float4 kb4 = *reinterpret_cast<const float4*>(kbias + kt * 64 + j * 16 + 4 * g);
+            const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[j][r] * scale;
-          if (need_mask) {
-            const int key = kt * 64 + j * 16 + 4 * g + r;
-            if (key > myq || !key_ok(am, b, key, P, T, S)) v = -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 64 + j * 16 + 4 * g + r;
+              float v = s[j][r] * scale2 + kbv[r];
+              v = key > myq ? -INFINITY : v;
+              s[j][r] = v;
+              tmax = fmaxf(tmax, v);
+            }
+          } else {
+            s[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
           }
-          s[j][r] = v;
-          tmax = fmaxf(tmax, v);
         }
-      tmax = col_max(tmax);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = s[j][r] * scale2;
+            s[j][r] = v;
+            tmax = fmaxf(tmax, v);
+          }
+      }
+      tmax = col_max_sw(tmax);
       const float mn = fmaxf(m, tmax);
-      const float alpha = __expf(m - mn);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
       m = mn;
       float ps = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(s[j][r] - mn);
+          const float pv = __builtin_amdgcn_exp2f(s[j][r] - mn);
           s[j][r] = pv;
           ps += pv;
         }
       l = l * alpha + ps;
 #pragma unroll
       for (int i = 0; i < D / 16; ++i) o[i] *= alpha;
-      const bf16x8 p0 = pack_acc(s[0], s[1]), p1 = pack_acc(s[2], s[3]);
+      const bf16x8 p0 = pack_acc(s[0], s[1]);
 #pragma unroll
-      for (int dt = 0; dt < D / 16; ++dt) {
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2, lane), p0, o[dt], 0, 0, 0);
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2 + 1, lane), p1, o[dt], 0, 0, 0);
+      for (int dt = 0; dt < D / 16; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2, lane), p0, o[dt], 0, 0, 0);
+      if (nj > 2) {
+        const bf16x8 p1 = pack_acc(s[2], s[3]);
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2 + 1, lane), p1, o[dt], 0, 0, 0);
       }
     }
-    l = col_sum(l);
+    l = col_sum_sw(l);
     if (myq < S) {
       const float inv = 1.0f / l;
       bf16_t* op = out + ((int64_t)b * S + myq) * H * D + (int64_t)h * D;
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt)
         store4(op + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
-      if (g == 0) lse[((int64_t)b * H + h) * S + myq] = m + logf(l);
+      if (g == 0) lse[((int64_t)b * H + h) * S + myq] = m * MAFED_LN2 + logf(l);
     }
   }
 }
@@ -623,12 +731,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
                                                               float* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int spad = (S + 63) / 64 * 64;
+  const int nrows = (S + 31) / 32 * 32;
   char* kimg = lds;
-  char* vimg = lds + spad * D * 2;
+  char* vimg = lds + nrows * D * 2;
+  float* kbias = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
   const int64_t rstride = (int64_t)H * 3 * D;
   const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
   const bf16_t* kb = qb + D;
@@ -636,78 +746,105 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
   const int64_t ostride = (int64_t)H * D;
   const bf16_t* ob = out + (int64_t)b * S * ostride + (int64_t)h * D;
   const bf16_t* dob = dout + (int64_t)b * S * ostride + (int64_t)h * D;
-  stage_all_rows<D, true>(kimg, kb, rstride, spad, S, rot, rc, rs, tid);
-  stage_all_rows<D, false>(vimg, vb, rstride, spad, S, rot, rc, rs, tid);
+  const float* Lrow = lse + ((int64_t)b * H + h) * S;
+  const int nslices = (S + 15) / 16;
+  const int hc = rot >> 4, items = S * hc;
+  dma_rows<D>(kimg, kb, rstride, nrows, S, wave, lane);
+  dma_rows<D>(vimg, vb, rstride, nrows, S, wave, lane);
+  RotPre pre[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + 256 * u < items) rot_pre_load(pre[u], tid + 256 * u, hc, rot, rc, rs);
+  for (int k = tid; k < nrows; k += 256) kbias[k] = key_ok(am, b, k, P, T, S) ? 0.f : -INFINITY;
+  ColRaw<D> qraw, doraw, oraw;
+  float Lnext = 0.f;
+  {
+    const int s0 = nslices - 1 - snake4(wave, 0);
+    if (s0 >= 0) {
+      col_raw_issue<D, true>(qraw, qb, rstride, s0 * 16, S, rot, rc, rs, lane);
+      col_raw_issue<D, false>(doraw, dob, ostride, s0 * 16, S, 0, rc, rs, lane);
+      col_raw_issue<D, false>(oraw, ob, ostride, s0 * 16, S, 0, rc, rs, lane);
+      const int q = s0 * 16 + (lane & 15);
+      Lnext = q < S ? Lrow[q] : 0.f;
+    }
+  }
+  wait_vm0();
+  __syncthreads();
+  rot_fix_rows<D>(kimg, items, hc, rot, rc, rs, pre, tid);
   __syncthreads();
   const int g = lane >> 4;
   const float scale = rsqrtf((float)D);
-  const int nslices = (S + 15) / 16;
-  ColRaw<D> qraw, doraw, oraw;
-  {
-    const int s0 = zigzag_slice(wave, 0) * 16;
-    col_raw_issue<D, true>(qraw, qb, rstride, s0, S, rot, rc, rs, lane);
-    col_raw_issue<D, false>(doraw, dob, ostride, s0, S, 0, rc, rs, lane);
-    col_raw_issue<D, false>(oraw, ob, ostride, s0, S, 0, rc, rs, lane);
-  }
+  const float scale2 = scale * MAFED_LOG2E;
   for (int t = 0;; ++t) {
-    const int slice = zigzag_slice(wave, t);
-    if (slice >= nslices) break;
+    const int slice = nslices - 1 - snake4(wave, t);
+    if (slice < 0) break;
     const int q0 = slice * 16;
     const int myq = q0 + (lane & 15);
     bf16x8 qf[D / 32], dof[D / 32];
     col_raw_finish<D, true>(qf, qraw, q0, S, rot, lane);
     col_raw_finish<D, false>(dof, doraw, q0, S, 0, lane);
+    const float L2 = Lnext * MAFED_LOG2E;
     float dl = 0.f;
     {
       bf16x8 of[D / 32];
       col_raw_finish<D, false>(of, oraw, q0, S, 0, lane);
-      const int nxt = zigzag_slice(wave, t + 1);
-      if (nxt < nslices) {
+      const int nxt = nslices - 1 - snake4(wave, t + 1);
+      if (nxt >= 0) {
         col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
         col_raw_issue<D, false>(doraw, dob, ostride, nxt * 16, S, 0, rc, rs, lane);
         col_raw_issue<D, false>(oraw, ob, ostride, nxt * 16, S, 0, rc, rs, lane);
+        const int q = nxt * 16 + (lane & 15);
+        Lnext = q < S ? Lrow[q] : 0.f;
       }
 #pragma unroll
       for (int ks = 0; ks < D / 32; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[ks][e];
-      dl = col_sum(dl);
+      dl = col_sum_sw(dl);
     }
-    float L = 0.f;
-    if (myq < S) {
-      L = lse[((int64_t)b * H + h) * S + myq];
-      if (g == 0) delta[((int64_t)b * H + h) * S + myq] = dl;
-    }
+    if (myq < S && g == 0) delta[((int64_t)b * H + h) * S + myq] = dl;
     f32x4 dq[D / 16];
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int last_kt = (q0 + 15) / 64;
     for (int kt = 0; kt <= last_kt; ++kt) {
+      const int nj = kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4;
       const bool need_mask = (kt == last_kt) || (kt * 64 + 63 >= P);
       f32x4 ds[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ds[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < nj) {
+          f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(vimg, kt * 4 + j, ks, lane), dof[ks], dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pv = __expf(s[r] * scale - L);
-          if (need_mask) {
-            const int key = kt * 64 + j * 16 + 4 * g + r;
-            if (key > myq || !key_ok(am, b, key, P, T, S)) pv = 0.f;
+          for (int ks = 0; ks < D / 32; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(vimg, kt * 4 + j, ks, lane), dof[ks], dp, 0, 0, 0);
           }
-          ds[j][r] = pv * (dp[r] - dl) * scale;
+          if (need_mask) {
+            const float4 kb4 = *reinterpret_cast<const float4*>(kbias + kt * 64 + j * 16 + 4 * g);
+            const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 64 + j * 16 + 4 * g + r;
+              float x = s[r] * scale2 - L2 + kbv[r];
+              x = key > myq ? -INFINITY : x;
+              ds[j][r] = __builtin_amdgcn_exp2f(x) * (dp[r] - dl) * scale;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[j][r] = __builtin_amdgcn_exp2f(s[r] * scale2 - L2) * (dp[r] - dl) * scale;
+          }
         }
       }
-      const bf16x8 d0 = pack_acc(ds[0], ds[1]), d1 = pack_acc(ds[2], ds[3]);
+      const bf16x8 d0 = pack_acc(ds[0], ds[1]);
 #pragma unroll
-      for (int dt = 0; dt < D / 16; ++dt) {
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2, lane), d0, dq[dt], 0, 0, 0);
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2 + 1, lane), d1, dq[dt], 0, 0, 0);
+      for (int dt = 0; dt < D / 16; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2, lane), d0, dq[dt], 0, 0, 0);
+      if (nj > 2) {
+        const bf16x8 d1 = pack_acc(ds[2], ds[3]);
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2 + 1, lane), d1, dq[dt], 0, 0, 0);
       }
     }
     bf16_t* dqp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)myq * rstride;
@@ -715,51 +852,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
   }
 }
 
-// dK / dV: Q (rotated) and dO of the head are resident; each wave owns 16-key slices, heaviest (lowest keys) first
+// dK / dV: Q (rotated) and dO of the head are resident, with the rows' log2-domain LSE and delta beside them; each wave
+// owns 16-key slices, heaviest (lowest keys) first
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta, AttnShape sh,
                                                                const float* __restrict__ rc, const float* __restrict__ rs,
                                                                const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int spad = (S + 63) / 64 * 64;
+  const int nrows = (S + 31) / 32 * 32;
   char* qimg = lds;
-  char* doimg = lds + spad * D * 2;
+  char* doimg = lds + nrows * D * 2;
+  float* L2s = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
+  float* Ds = L2s + nrows;
   const int64_t rstride = (int64_t)H * 3 * D;
   const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
   const bf16_t* kb = qb + D;
   const bf16_t* vb = qb + 2 * D;
   const int64_t ostride = (int64_t)H * D;
   const bf16_t* dob = dout + (int64_t)b * S * ostride + (int64_t)h * D;
-  stage_all_rows<D, true>(qimg, qb, rstride, spad, S, rot, rc, rs, tid);
-  stage_all_rows<D, false>(doimg, dob, ostride, spad, S, 0, rc, rs, tid);
+  const float* Lrow = lse + ((int64_t)b * H + h) * S;
+  const float* Drow = delta + ((int64_t)b * H + h) * S;
+  const int nslices = (S + 15) / 16;
+  const int hc = rot >> 4, items = S * hc;
+  dma_rows<D>(qimg, qb, rstride, nrows, S, wave, lane);
+  dma_rows<D>(doimg, dob, ostride, nrows, S, wave, lane);
+  RotPre pre[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + 256 * u < items) rot_pre_load(pre[u], tid + 256 * u, hc, rot, rc, rs);
+  for (int q = tid; q < nrows; q += 256) {
+    L2s[q] = q < S ? Lrow[q] * MAFED_LOG2E : INFINITY;  // rows past S: exp2(x - inf) = 0
+    Ds[q] = q < S ? Drow[q] : 0.f;
+  }
+  ColRaw<D> kraw, vraw;
+  {
+    const int s0 = snake4(wave, 0);
+    if (s0 < nslices) {
+      col_raw_issue<D, true>(kraw, kb, rstride, s0 * 16, S, rot, rc, rs, lane);
+      col_raw_issue<D, false>(vraw, vb, rstride, s0 * 16, S, 0, rc, rs, lane);
+    }
+  }
+  wait_vm0();
+  __syncthreads();
+  rot_fix_rows<D>(qimg, items, hc, rot, rc, rs, pre, tid);
   __syncthreads();
   const int g = lane >> 4;
   const float scale = rsqrtf((float)D);
-  const int nslices = (S + 15) / 16;
-  const int nqt = spad / 64;
-  const float* Lrow = lse + ((int64_t)b * H + h) * S;
-  const float* Drow = delta + ((int64_t)b * H + h) * S;
-  ColRaw<D> kraw, vraw;
-  {
-    const int s0 = zigzag_slice(wave, 0) * 16;
-    col_raw_issue<D, true>(kraw, kb, rstride, s0, S, rot, rc, rs, lane);
-    col_raw_issue<D, false>(vraw, vb, rstride, s0, S, 0, rc, rs, lane);
-  }
+  const float scale2 = scale * MAFED_LOG2E;
+  const int nqt = (nrows + 63) / 64;
   for (int t = 0;; ++t) {
-    const int slice = zigzag_slice(wave, t);
+    const int slice = snake4(wave, t);
     if (slice >= nslices) break;
     const int k0 = slice * 16;
     const int mykey = k0 + (lane & 15);
-    const bool mykey_ok = key_ok(am, b, mykey, P, T, S);
+    const int mykey_eff = key_ok(am, b, mykey, P, T, S) ? mykey : 0x7fffffff;  // a padded key is "after" every query
     bf16x8 kf[D / 32], vf[D / 32];
     col_raw_finish<D, true>(kf, kraw, k0, S, rot, lane);
     col_raw_finish<D, false>(vf, vraw, k0, S, 0, lane);
     {
-      const int nxt = zigzag_slice(wave, t + 1);
+      const int nxt = snake4(wave, t + 1);
       if (nxt < nslices) {
         col_raw_issue<D, true>(kraw, kb, rstride, nxt * 16, S, rot, rc, rs, lane);
         col_raw_issue<D, false>(vraw, vb, rstride, nxt * 16, S, 0, rc, rs, lane);
@@ -768,34 +924,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const bf16_t* __r
     f32x4 dk[D / 16], dv[D / 16];
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int qt = k0 / 64; qt < nqt; ++qt) {
+    const int qt0 = k0 / 64;
+    const bool text_keys = k0 + 15 >= P;
+    for (int qt = qt0; qt < nqt; ++qt) {
+      const int jlo = qt == qt0 ? (k0 - qt * 64) >> 4 : 0;           // query sub-tiles entirely before the slice's keys are skipped
+      const int jhi = (nrows - qt * 64) >> 4 < 4 ? (nrows - qt * 64) >> 4 : 4;
+      const bool need_mask = (qt == qt0) || text_keys;
       f32x4 p[4], ds[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        p[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ds[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j >= jlo && j < jhi) {
+          f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(qimg, qt * 4 + j, ks, lane), kf[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(doimg, qt * 4 + j, ks, lane), vf[ks], dp, 0, 0, 0);
-        }
+          for (int ks = 0; ks < D / 32; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(qimg, qt * 4 + j, ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(doimg, qt * 4 + j, ks, lane), vf[ks], dp, 0, 0, 0);
+          }
+          const float4 L4 = *reinterpret_cast<const float4*>(L2s + qt * 64 + j * 16 + 4 * g);
+          const float4 D4 = *reinterpret_cast<const float4*>(Ds + qt * 64 + j * 16 + 4 * g);
+          const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = qt * 64 + j * 16 + 4 * g + r;
-          const bool ok = mykey_ok && mykey <= q && q < S;
-          const float Lq = ok ? Lrow[q] : 0.f, Dq = ok ? Drow[q] : 0.f;
-          const float pv = ok ? __expf(s[r] * scale - Lq) : 0.f;
-          p[j][r] = pv;
-          ds[j][r] = pv * (dp[r] - Dq) * scale;
+          for (int r = 0; r < 4; ++r) {
+            float x = s[r] * scale2 - Lv[r];
+            if (need_mask) {
+              const int q = qt * 64 + j * 16 + 4 * g + r;
+              x = mykey_eff > q ? -INFINITY : x;
+            }
+            const float pv = __builtin_amdgcn_exp2f(x);
+            p[j][r] = pv;
+            ds[j][r] = pv * (dp[r] - Dv[r]) * scale;
+          }
         }
       }
-      const bf16x8 p0 = pack_acc(p[0], p[1]), p1 = pack_acc(p[2], p[3]);
-      const bf16x8 d0 = pack_acc(ds[0], ds[1]), d1 = pack_acc(ds[2], ds[3]);
+      if (jlo < 2) {
+        const bf16x8 p0 = pack_acc(p[0], p[1]), d0 = pack_acc(ds[0], ds[1]);
 #pragma unroll
-      for (int dt = 0; dt < D / 16; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, qt * 2, lane), p0, dv[dt], 0, 0, 0);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, qt * 2 + 1, lane), p1, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2, lane), d0, dk[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2 + 1, lane), d1, dk[dt], 0, 0, 0);
+        for (int dt = 0; dt < D / 16; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, qt * 2, lane), p0, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2, lane), d0, dk[dt], 0, 0, 0);
+        }
+      }
+      if (jhi > 2) {
+        const bf16x8 p1 = pack_acc(p[2], p[3]), d1 = pack_acc(ds[2], ds[3]);
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(doimg, dt, qt * 2 + 1, lane), p1, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2 + 1, lane), d1, dk[dt], 0, 0, 0);
+        }
       }
     }
     bf16_t* dkp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)mykey * rstride + D;
@@ -809,8 +986,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const bf16_t* __r
 }
 
 static bool attn_resident_fits(const AttnShape& sh, size_t* bytes) {
-  const size_t spad = (size_t)(sh.S + 63) / 64 * 64;
-  *bytes = spad * sh.D * 2 * 2;
+  const size_t nrows = (size_t)(sh.S + 31) / 32 * 32;
+  *bytes = nrows * sh.D * 2 * 2 + nrows * 4 * 2;  // two operand images + two fp32 rows (key bias | LSE, delta)
   return *bytes <= 160 * 1024;
 }
 static int g_attn_variant = 0;  // 0 automatic, 1 force the tiled kernels (tests)

@@ -25,6 +25,7 @@ SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
     ("proj  NT", False, True, 8192, 1024, 1024, torch.bfloat16),
 ]
 EPI = os.environ.get("GEMM_BENCH_EPI", "0") == "1"   # fc1 with bias + GELU + saved pre-activation, dfc2 with GELU'
+LIBREF = os.environ.get("GEMM_BENCH_LIB", "0") == "1"  # add a torch.matmul (hipBLASLt/rocBLAS) column as a yardstick
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
 lib = _lib.load()
 g = torch.Generator(device=dev).manual_seed(0)
@@ -63,7 +64,21 @@ for name, tA, tB, m, n, k, od in SHAPES:
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 10)
     fl = 2.0 * m * n * k
+    lib_col = ""
+    if LIBREF:   # yardstick only: the vendor library on the same operands (plain product, no epilogue, bf16 output)
+        At, Bt = (A.t() if tA else A), (B.t() if tB else B)
+        o2 = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        tl = []
+        for rnd in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                torch.matmul(At, Bt, out=o2)
+            e1.record()
+            torch.cuda.synchronize()
+            tl.append(e0.elapsed_time(e1) / 10)
+        lib_col = f"  lib: {min(tl)*1e3:7.1f} us {fl/min(tl)/1e9:7.1f} TF"
     line = f"{name} {m}x{n}x{k}: " + "  ".join(f"v{v}: {min(t)*1e3:7.1f} us {fl/min(t)/1e9:7.1f} TF" for v, t in times.items())
-    print(line, flush=True)
+    print(line + lib_col, flush=True)
 lib.mafed_gemm_set_variant(0)
 lib.mafed_gemm_set_variant(100)
