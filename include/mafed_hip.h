@@ -60,6 +60,16 @@ int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t 
                const float* bias, int epilogue, void* aux,
                const float* res1, const float* res2, float beta, void* stream);
 
+/* mafed_gemm that also accumulates the column sums of the stored C: colsum[n] += sum_m C[m,n] (fp32 [N], may be NULL;
+ * beta must be 0).  This is the bias gradient of the nn.Linear whose output gradient this GEMM produces
+ * (dense_h_to_4h.bias from the GELU' epilogue of dX = dY.W2), fused into the epilogue of the MFMA kernel instead of
+ * a second pass over C; where the selected kernel has no fused form the library runs mafed_colsum itself. */
+int mafed_gemm_colsum(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                      const void* A, int64_t lda, const void* B, int64_t ldb,
+                      void* C, int64_t ldc, mafed_dtype c_dtype,
+                      const float* bias, int epilogue, void* aux,
+                      const float* res1, const float* res2, float beta, float* colsum, void* stream);
+
 /* out[n] += sum_m X[m,n]   (bias gradients; X dtype bf16/f32, out fp32 accumulated with one atomic per column per
  * 256-row block; N, ldx multiples of 4).  workspace is unused (kept for ABI stability; workspace_bytes may be 0). */
 size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N);
@@ -109,6 +119,12 @@ int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, int H, int 
 int mafed_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype,
                    int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                    const int64_t* attention_mask, int T, void* dqkv, float* delta, void* stream);
+/* mafed_attn_bwd that also accumulates dqkv_colsum[3*H*D] += sum over the B*S rows of dqkv: the gradient of
+ * query_key_value.bias (tf:192), folded inside the resident MFMA kernels (one run of atomics per block) instead of a
+ * second pass over dqkv; other paths run mafed_colsum themselves.  dqkv_colsum may be NULL. */
+int mafed_attn_bwd_colsum(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype,
+                          int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                          const int64_t* attention_mask, int T, void* dqkv, float* delta, float* dqkv_colsum, void* stream);
 
 /* ---- embedding + concat (mafed/model/vl_pythia.py:282-283) ---------------------------------------------------
  * h0[b, :P] = image[b] ; h0[b, P:] = embed_in[input_ids[b]]  -> fp32 [B,P+T,h].  image in img_dtype [B,P,h]. */

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mafed_version": (_i, []),
     "mafed_last_error_string": (C.c_char_p, []),
     "mafed_gemm": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p]),
+    "mafed_gemm_colsum": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p, _p]),
     "mafed_gemm_set_variant": (_i, [_i]),
     "mafed_colsum_workspace_bytes": (_z, [_l, _l]),
     "mafed_colsum": (_i, [_p, _i, _l, _l, _l, _p, _p, _z, _p]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "mafed_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _p, _p, _p, _z, _p]),
     "mafed_attn_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_attn_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "mafed_attn_bwd_colsum": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "mafed_attn_set_variant": (_i, [_i]),
     "mafed_attn_fwd_exact_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_embed_concat_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _l, _p, _p]),

@@ -18,7 +18,7 @@ int attn_ref_bwd_launch(const void* qkv, const void* out, const void* dout, cons
 int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
                          hipStream_t st);
 int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
-                         const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st);
+                         const float* rs, const int64_t* am, void* dqkv, float* delta, float* colsum, bool* colsum_done, hipStream_t st);
 
 void attn_mfma_set_variant(int v);  // 0 automatic (resident kernels when K/V fit in LDS), 1 tiled kernels only
 

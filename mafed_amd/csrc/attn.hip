@@ -36,27 +36,46 @@ extern "C" int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, 
   return MAFED_OK;
 }
 
+static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype, int B, int S, int H,
+                         int D, int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* dqkv,
+                         float* delta, float* dqkv_colsum, void* stream);
+
 extern "C" int mafed_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype, int B, int S, int H,
                               int D, int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* dqkv,
                               float* delta, void* stream) {
+  return attn_bwd_impl(qkv, out, dout, lse, dtype, B, S, H, D, rot, rot_cos, rot_sin, attention_mask, T, dqkv, delta, nullptr, stream);
+}
+
+extern "C" int mafed_attn_bwd_colsum(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype, int B, int S,
+                                     int H, int D, int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T,
+                                     void* dqkv, float* delta, float* dqkv_colsum, void* stream) {
+  return attn_bwd_impl(qkv, out, dout, lse, dtype, B, S, H, D, rot, rot_cos, rot_sin, attention_mask, T, dqkv, delta, dqkv_colsum, stream);
+}
+
+static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype, int B, int S, int H,
+                         int D, int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* dqkv,
+                         float* delta, float* dqkv_colsum, void* stream) {
   int rc = check_common("attn_bwd", qkv, B, S, H, D, rot, rot_cos, rot_sin, attention_mask, T);
   if (rc) return rc;
   MAFED_CHECK_ARG(out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
   AttnShape sh{B, S, H, D, rot, T, S - T};
   hipStream_t st = as_stream(stream);
+  bool colsum_done = false;  // the resident MFMA kernels fold the column sums of dqkv themselves
   if (dtype == MAFED_F32) {
     MAFED_CHECK_ARG(D <= 256, "attn_bwd(f32): D=%d > 256", D);
     rc = attn_ref_bwd_launch<float>(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, st);
   } else if (mfma_ok(D, rot)) {
     MAFED_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0,
                     "attn_bwd(bf16): tensors must be 16-byte aligned");
-    rc = attn_mfma_bwd_launch(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, st);
+    rc = attn_mfma_bwd_launch(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, dqkv_colsum, &colsum_done, st);
   } else {
     MAFED_CHECK_ARG(D <= 256, "attn_bwd(bf16): D=%d > 256", D);
     rc = attn_ref_bwd_launch<bf16_t>(qkv, out, dout, lse, sh, rot_cos, rot_sin, attention_mask, dqkv, delta, st);
   }
   if (rc) return rc;
   MAFED_CHECK_LAUNCH("attn_bwd");
+  if (dqkv_colsum && !colsum_done)
+    return mafed_colsum(dqkv, dtype, (int64_t)B * S, (int64_t)3 * H * D, (int64_t)3 * H * D, dqkv_colsum, nullptr, 0, stream);
   return MAFED_OK;
 }
 

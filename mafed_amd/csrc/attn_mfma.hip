@@ -579,6 +579,15 @@ __device__ __forceinline__ void rot_fix_rows(char* __restrict__ img, int items, 
   }
 }
 
+// sum over the 16 lanes of a DPP row; every lane ends with the row total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // slice of wave w in round t: rounds of 4 slices, direction alternating, from the heaviest slice down
@@ -729,13 +738,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse, AttnShape sh,
                                                               const float* __restrict__ rc, const float* __restrict__ rs,
                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
-                                                              float* __restrict__ delta) {
+                                                              float* __restrict__ delta, float* __restrict__ bsum) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
   const int nrows = (S + 31) / 32 * 32;
+  f32x4 bs[D / 16];  // running column sums of the stored dq rows (query_key_value.bias gradient), when asked for
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) bs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   char* kimg = lds;
   char* vimg = lds + nrows * D * 2;
   float* kbias = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
@@ -849,22 +861,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
     }
     bf16_t* dqp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)myq * rstride;
     store_grad_unrot<D>(dqp, dq, rot, rc, rs, myq, lane, myq < S);
+    if (bsum && myq < S) {
+#pragma unroll
+      for (int i = 0; i < D / 16; ++i) bs[i] += dq[i];
+    }
+  }
+  if (bsum) {  // fold the 16 queries of a lane row, then the four waves, then one 4*D-byte run of atomics per block
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = row16_sum(bs[dt][r]);
+        if ((lane & 15) == 0) red[wave * D + dt * 16 + 4 * (lane >> 4) + r] = v;
+      }
+    __syncthreads();
+    if (tid < D) atomicAdd(bsum + (int64_t)h * 3 * D + tid, red[tid] + red[D + tid] + red[2 * D + tid] + red[3 * D + tid]);
   }
 }
 
 // dK / dV: Q (rotated) and dO of the head are resident, with the rows' log2-domain LSE and delta beside them; each wave
 // owns 16-key slices, heaviest (lowest keys) first
+// (two waves per SIMD at D = 64 -- the LDS footprint allows two blocks per CU, so the register budget is capped to match)
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta, AttnShape sh,
                                                                const float* __restrict__ rc, const float* __restrict__ rs,
-                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv) {
+                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
+                                                               float* __restrict__ bsum) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
   const int nrows = (S + 31) / 32 * 32;
+  f32x4 bsk[D / 16], bsv[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) { bsk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; bsv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   char* qimg = lds;
   char* doimg = lds + nrows * D * 2;
   float* L2s = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
@@ -981,7 +1015,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const bf16_t* __r
       bf16_t* dvp = dkp + D;
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) store4(dvp + dt * 16 + 4 * g, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
+      if (bsum) {
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) { bsk[i] += dk[i]; bsv[i] += dv[i]; }
+      }
     }
+  }
+  if (bsum) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);  // [4 waves][dk D | dv D]
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float vk = row16_sum(bsk[dt][r]), vv = row16_sum(bsv[dt][r]);
+        if ((lane & 15) == 0) {
+          red[wave * 2 * D + dt * 16 + 4 * (lane >> 4) + r] = vk;
+          red[wave * 2 * D + D + dt * 16 + 4 * (lane >> 4) + r] = vv;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * D) atomicAdd(bsum + (int64_t)h * 3 * D + D + tid, red[tid] + red[2 * D + tid] + red[4 * D + tid] + red[6 * D + tid]);
   }
 }
 
@@ -1018,23 +1072,25 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
 }
 
 int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
-                         const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st) {
+                         const float* rs, const int64_t* am, void* dqkv, float* delta, float* colsum, bool* colsum_done, hipStream_t st) {
   size_t bytes;
+  *colsum_done = false;
   if (g_attn_variant != 1 && attn_resident_fits(sh, &bytes)) {
     dim3 grid(sh.H, sh.B), block(256);
     if (sh.D == 64) {
       set_lds_attr(attn_bwd_dq_res_kernel<64>, bytes);
       set_lds_attr(attn_bwd_dkv_res_kernel<64>, bytes);
       attn_bwd_dq_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
-                                                             (bf16_t*)dqkv, delta);
-      attn_bwd_dkv_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
+                                                             (bf16_t*)dqkv, delta, colsum);
+      attn_bwd_dkv_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv, colsum);
     } else {
       set_lds_attr(attn_bwd_dq_res_kernel<128>, bytes);
       set_lds_attr(attn_bwd_dkv_res_kernel<128>, bytes);
       attn_bwd_dq_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
-                                                              (bf16_t*)dqkv, delta);
-      attn_bwd_dkv_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
+                                                              (bf16_t*)dqkv, delta, colsum);
+      attn_bwd_dkv_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv, colsum);
     }
+    *colsum_done = colsum != nullptr;
     return MAFED_OK;
   }
   dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
       return;
     }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), j = lane & 7;
@@ -438,11 +439,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       epilogue_store8<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v);
+      if (epi.colsum) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cs[i] += v[i];
+      }
     }
+    if (epi.colsum) colsum_flush<8>(cs, epi.colsum, n0 + wn * 64, lane);
   } else if constexpr (MT == 6 && NT == 4 && STAGE * 2 >= NW * 12288) {
     // 96 x 64 wave tile (192 x 128 block): two passes of 3 row tiles through a wave-private 48 x 64 fp32 region
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -462,13 +469,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
         const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         epilogue_store8<CT>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v);
+        if (epi.colsum) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cs[i] += v[i];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if (epi.colsum) colsum_flush<8>(cs, epi.colsum, n0 + wn * 64, lane);
   } else if constexpr (MT == 9 && NT == 4 && STAGE * 2 >= NW * 12288) {
     // 144 x 64 wave tile (288 x 256 block): three passes of 3 row tiles through a wave-private 48 x 64 fp32 region
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
@@ -488,13 +501,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
         const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         epilogue_store8<CT>(epi, C, m0 + (wm * 9 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v);
+        if (epi.colsum) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cs[i] += v[i];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if (epi.colsum) colsum_flush<8>(cs, epi.colsum, n0 + wn * 64, lane);
   } else if constexpr (MT == 9 && NT == 2 && WM == 1 && STAGE * 2 >= NW * 10240) {
     // 144 x 32 wave tile: same idea in two passes (row tiles 0-4, then 5-8) through a wave-private 80 x 32 fp32 region
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 2560;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int mt0 = pass * 5, nmt = pass == 0 ? 5 : 4;
@@ -518,10 +537,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
           const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j + 1) ^ (row & 7)) << 2));
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           epilogue_store8<CT>(epi, C, m0 + mt0 * 16 + row, n0 + wn * 32 + 8 * j, v);
+          if (epi.colsum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs[i] += v[i];
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if (epi.colsum) colsum_flush<4>(cs, epi.colsum, n0 + wn * 32, lane);
   } else {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -882,9 +906,25 @@ extern "C" int mafed_gemm_set_variant(int v) {
   return MAFED_OK;
 }
 
+static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                     const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
+                     void* aux, const float* res1, const float* res2, float beta, float* colsum, void* stream);
+
 extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                           const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
                           void* aux, const float* res1, const float* res2, float beta, void* stream) {
+  return gemm_impl(in_dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, epilogue, aux, res1, res2, beta, nullptr, stream);
+}
+
+extern "C" int mafed_gemm_colsum(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                                 const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
+                                 void* aux, const float* res1, const float* res2, float beta, float* colsum, void* stream) {
+  return gemm_impl(in_dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, epilogue, aux, res1, res2, beta, colsum, stream);
+}
+
+static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                     const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
+                     void* aux, const float* res1, const float* res2, float beta, float* colsum, void* stream) {
   MAFED_CHECK_ARG(A && B && C, "gemm: null pointer");
   MAFED_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MAFED_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm: N=%lld and ldc=%lld must be multiples of 4 (vector epilogue)",
@@ -898,14 +938,19 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
   MAFED_CHECK_ARG((((uintptr_t)C | (uintptr_t)aux | (uintptr_t)res1 | (uintptr_t)res2 | (uintptr_t)bias) & 7) == 0,
                   "gemm: C/aux/res/bias must be at least 8-byte aligned");
   if (M == 0) return MAFED_OK;
-  GemmEpi epi{bias, epilogue, aux, res1, res2, res1_bf16, beta, ldc};
+  GemmEpi epi{bias, epilogue, aux, res1, res2, res1_bf16, beta, ldc, nullptr};
   hipStream_t st = as_stream(stream);
+  // column sums of C: fused into the LDS-staged epilogues of the MFMA kernel where that exists, otherwise a second pass
+  auto colsum_after = [&]() -> int {
+    return colsum ? mafed_colsum(C, c_dtype, M, N, ldc, colsum, nullptr, 0, stream) : MAFED_OK;
+  };
+  MAFED_CHECK_ARG(!colsum || beta == 0.f, "gemm: colsum with beta != 0 is not defined");
   if (in_dtype == MAFED_F32) {
     dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64)), block(256);
     if (c_dtype == MAFED_F32) gemm_f32_kernel<float><<<grid, block, 0, st>>>(transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, epi);
     else gemm_f32_kernel<bf16_t><<<grid, block, 0, st>>>(transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (bf16_t*)C, epi);
     MAFED_CHECK_LAUNCH("gemm(f32)");
-    return MAFED_OK;
+    return colsum_after();
   }
   // bf16 MFMA path: 16-byte operand loads along the contiguous extent
   MAFED_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0,
@@ -955,6 +1000,8 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
     g_gemm_nsplit = ns;
   }
   if (cfg >= 0) {
+    const bool fused_colsum = colsum && g_gemm_nsplit == 1 && (cfg == 0 || cfg == 11 || cfg == 16 || cfg == 17);
+    if (fused_colsum) epi.colsum = colsum;
 #define GOG(AKS, BKS)                                                                                                       \
   rc = (c_dtype == MAFED_F32) ? launch_bf16_glds_cfg<AKS, BKS, float>(cfg, M, N, K, A, lda, B, ldb, C, epi, st)             \
                               : launch_bf16_glds_cfg<AKS, BKS, bf16_t>(cfg, M, N, K, A, lda, B, ldb, C, epi, st)
@@ -965,7 +1012,7 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
 #undef GOG
     if (rc != MAFED_OK) return rc;
     MAFED_CHECK_LAUNCH("gemm(bf16, lds-dma)");
-    return MAFED_OK;
+    return fused_colsum ? MAFED_OK : colsum_after();
   }
 #define GO(AKS, BKS)                                                                                         \
   rc = (c_dtype == MAFED_F32) ? launch_bf16<AKS, BKS, float>(M, N, K, A, lda, B, ldb, C, epi, st)            \
@@ -977,5 +1024,5 @@ extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t 
 #undef GO
   if (rc != MAFED_OK) return rc;
   MAFED_CHECK_LAUNCH("gemm(bf16)");
-  return MAFED_OK;
+  return colsum_after();
 }

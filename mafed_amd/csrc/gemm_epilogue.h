@@ -13,6 +13,7 @@ struct GemmEpi {
   int res1_bf16;
   float beta;          // C = v + beta * C_old  (fp32 C only)
   int64_t ldc;
+  float* colsum;       // [N] or null: colsum[n] += sum_m C[m,n] (the bias gradient of the layer that produced this GEMM's input)
 };
 
 // 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N guaranteed by the caller)
@@ -118,6 +119,23 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
     for (int i = 0; i < 8; ++i) v[i] += e.beta * c[i];
   }
   store8(C + off, v);
+}
+
+// Fused column sums of the stored tile: cs[i] holds this lane's partial for column 8*(lane % JL)+i over the rows it
+// stored; lanes that share lane % JL are folded, then JL lanes issue 8 atomics each (one per column per wave per tile).
+template <int JL>
+__device__ __forceinline__ void colsum_flush(float (&cs)[8], float* __restrict__ colsum, int64_t ncol0, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = cs[i];
+#pragma unroll
+    for (int o = JL; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    cs[i] = v;
+  }
+  if (lane < JL) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(colsum + ncol0 + 8 * lane + i, cs[i]);
+  }
 }
 
 }  // namespace mafed

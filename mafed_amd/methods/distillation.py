@@ -183,7 +183,8 @@ class FeatureDistillation(CLStrategy):
         n_ex = batch["input_ids"].size(0)
         do_replay = self.replay_coeff > 0 and self.task_id > 0
         if self.distillation_coeff != 0:
-            self._prefetch_teacher(batch)  # frozen-teacher forward on a second HIP stream, concurrent with the student's
+            # frozen-teacher forward on a second HIP stream, concurrent with the student's
+            self._prefetch_teacher(batch, getattr(self.mem_dataloader, "last_ready_event", None))
         output = model(**batch, compute_loss=do_replay, output_hidden_states=True, return_dict=True)
         loss = self.replay_coeff * output.loss if do_replay else None
         if self.distillation_coeff == 0:
@@ -192,7 +193,7 @@ class FeatureDistillation(CLStrategy):
         loss = dloss if loss is None else loss + dloss
         return loss, n_ex
 
-    def _prefetch_teacher(self, batch):
+    def _prefetch_teacher(self, batch, batch_ready_event=None):
         """Issue the teacher forward on its own stream before the student's (same arithmetic, earlier in time): the two
         forwards are independent kernel chains, so their wave-quantisation tails fill each other on the 256 CUs."""
         self._prefetched = None
@@ -203,13 +204,18 @@ class FeatureDistillation(CLStrategy):
         main = torch.cuda.current_stream()
         side = pm.side_stream()
         # Order behind the previous step's backward (the last reader of the previous teacher states, whose memory this
-        # forward re-uses) -- NOT behind its optimiser: the frozen teacher does not depend on the update, so its forward
-        # overlaps the HBM-bound clip + AdamW tail of the previous step.
+        # forward re-uses) ...
         ev_prev = getattr(self, "backward_done_event", None)
         if ev_prev is not None:
             side.wait_event(ev_prev)
-        else:
-            side.wait_stream(main)
+        # ... and behind whatever produced this batch.  A loader that gathers on its own stream (HBMReplayBuffer) hands
+        # out the batch's event: the teacher forward then does NOT wait for the caller's stream, i.e. it overlaps the
+        # HBM-bound clip + AdamW tail of the previous step (the frozen teacher does not depend on the update).
+        # Otherwise: everything queued on the caller's stream so far.
+        side.wait_event(batch_ready_event if batch_ready_event is not None else main.record_event())
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(side)
         kw = {"patch_embeddings": batch["patch_embeddings"]} if "patch_embeddings" in batch else {"pixel_values": batch["pixel_values"]}
         with torch.cuda.stream(side):
             hs = [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=max(layers) + 1, **kw)]

@@ -28,6 +28,12 @@ class HBMReplayBuffer:
         self.data: Dict[str, Optional[torch.Tensor]] = {k: None for k in self.KEYS}
         self.gen = torch.Generator(device="cpu")
         self.gen.manual_seed(seed)
+        # GPU: the next batch is gathered one draw ahead on a loader stream (a DataLoader's prefetch), so that consumers
+        # that run beside the caller's stream -- the frozen-teacher forward -- can start on it before the caller's stream
+        # has drained the previous step's optimiser.  ``last_ready_event`` marks the batch handed out last.
+        self._next = None
+        self._stream = None
+        self.last_ready_event = None
 
     def __len__(self) -> int:
         t = self.data["input_ids"]
@@ -47,14 +53,44 @@ class HBMReplayBuffer:
                 cur = torch.nn.functional.pad(cur, (T - cur.shape[1], 0), value=fill)
                 v = torch.nn.functional.pad(v, (T - v.shape[1], 0), value=fill)
             self.data[k] = v if cur is None else torch.cat([cur, v], dim=0)
+        self._next = None  # a batch gathered ahead of time no longer reflects the buffer
 
     def sample(self) -> Dict[str, torch.Tensor]:
+        if self.device.type != "cuda":
+            return self._draw()
+        cur = torch.cuda.current_stream(self.device)
+        if self._next is None:
+            self._prefetch(cur)
+        batch, ev = self._next
+        cur.wait_event(ev)
+        for v in batch.values():
+            v.record_stream(cur)  # allocated on the loader stream, consumed here
+        self.last_ready_event = ev
+        self._prefetch(cur)
+        return batch
+
+    def _prefetch(self, cur) -> None:
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        self._stream.wait_stream(cur)  # the buffer contents (add) were written on the caller's stream
+        with torch.cuda.stream(self._stream):
+            batch = self._draw()
+            self._next = (batch, self._stream.record_event())
+
+    def _draw(self) -> Dict[str, torch.Tensor]:
         n = len(self)
         if n == 0:
             raise RuntimeError("replay memory is empty")
         lo, hi = (n * self.rank) // self.world_size, (n * (self.rank + 1)) // self.world_size
         m = max(1, hi - lo)
-        idx = (torch.randperm(m, generator=self.gen)[: self.batch_size] + lo).to(self.device)
+        idx = torch.randperm(m, generator=self.gen)[: self.batch_size] + lo
+        if self.device.type == "cuda":
+            # pinned + non_blocking: a pageable .to(device) synchronises the stream, i.e. the host could not start
+            # enqueueing step n+1 before the GPU had finished step n (the host allocator holds the pinned block until
+            # the copy has run)
+            idx = idx.pin_memory().to(self.device, non_blocking=True)
+        else:
+            idx = idx.to(self.device)
         return {k: v.index_select(0, idx) for k, v in self.data.items()}
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:

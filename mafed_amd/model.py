@@ -590,13 +590,16 @@ class VLPythiaForCausalLM(nn.Module):
             wgrad(dy, s["a"], pre + "mlp.dense_4h_to_h.weight", None if dy_bias_done else pre + "mlp.dense_4h_to_h.bias")
             wgrad(dy, s["ao"], pre + "attention.dense.weight", None if dy_bias_done else pre + "attention.dense.bias")
             # MLP branch
-            du = ops.gemm(dy, w(pre + "mlp.dense_4h_to_h.weight"), False, False, epilogue=EPI_GELU_BWD, aux=s["u"])
-            wgrad(du, s["ln2"], pre + "mlp.dense_h_to_4h.weight", pre + "mlp.dense_h_to_4h.bias")
+            # (the bias gradients of the two up-projections are column sums of du / dqkv: folded into the producing kernels)
+            du = ops.gemm(dy, w(pre + "mlp.dense_4h_to_h.weight"), False, False, epilogue=EPI_GELU_BWD, aux=s["u"],
+                          colsum=g(pre + "mlp.dense_h_to_4h.bias"))
+            wgrad(du, s["ln2"], pre + "mlp.dense_h_to_4h.weight")
             dln2 = ops.gemm(du, w(pre + "mlp.dense_h_to_4h.weight"), False, False)
             # attention branch
             dao = ops.gemm(dy, w(pre + "attention.dense.weight"), False, False)
-            dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, S, H, D, rot, cos, sin, am)
-            wgrad(dqkv, s["ln1"], pre + "attention.query_key_value.weight", pre + "attention.query_key_value.bias")
+            dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, S, H, D, rot, cos, sin, am,
+                                colsum=g(pre + "attention.query_key_value.bias"))
+            wgrad(dqkv, s["ln1"], pre + "attention.query_key_value.weight")
             dln1 = ops.gemm(dqkv, w(pre + "attention.query_key_value.weight"), False, False)
             # both LayerNorms + the residual path, one pass; also emits the compute-dtype copy the next layer's GEMMs read
             dx, dy = ops.layernorm_bwd(dln1, dln2, s["x"], s["mean"], s["rstd"], self._p(pre + "input_layernorm.weight"),
@@ -622,8 +625,9 @@ class VLPythiaForCausalLM(nn.Module):
             fc, u0, a0 = sv["proj"]
             dimg = ops.embed_concat_bwd(dx, sv["input_ids"], B, P, T, h, cfg.vocab_size, g("gpt_neox.embed_in.weight"), cd)
             wgrad(dimg, a0, "vision_embed_tokens.2.weight", "vision_embed_tokens.2.bias")
-            du0 = ops.gemm(dimg, w("vision_embed_tokens.2.weight"), False, False, epilogue=EPI_GELU_BWD, aux=u0)
-            wgrad(du0, fc, "vision_embed_tokens.0.weight", "vision_embed_tokens.0.bias")
+            du0 = ops.gemm(dimg, w("vision_embed_tokens.2.weight"), False, False, epilogue=EPI_GELU_BWD, aux=u0,
+                           colsum=g("vision_embed_tokens.0.bias"))
+            wgrad(du0, fc, "vision_embed_tokens.0.weight")
         ready(-1)
         if sides is not None:
             for st in sides:

@@ -77,8 +77,9 @@ GEMM_EVENTS = None
 def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Optional[torch.Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
          aux: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
-         beta: float = 0.0) -> torch.Tensor:
-    """C = op(A) @ op(B) with the fused epilogue of mafed_gemm.  A, B 2-D, same dtype (bf16 -> MFMA, f32 -> exact)."""
+         beta: float = 0.0, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = op(A) @ op(B) with the fused epilogue of mafed_gemm.  A, B 2-D, same dtype (bf16 -> MFMA, f32 -> exact).
+    ``colsum`` (fp32 [N]): += the column sums of the stored C (mafed_gemm_colsum)."""
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
     assert A.stride(1) == 1 and B.stride(1) == 1
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -94,8 +95,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _fn.gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
-                  out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream())
+    if colsum is None:
+        rc = _fn.gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
+                      out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream())
+    else:
+        assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
+        rc = _fn.gemm_colsum(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
+                             out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta),
+                             _ptr(colsum), _stream())
     if rc:
         check(rc, "mafed_gemm")
     if prof:
@@ -158,12 +165,19 @@ def attn_fwd_exact_bf16(qkv, B, S, H, D, rot, cos, sin, attention_mask):
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, attention_mask):
+def attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, attention_mask, colsum: Optional[torch.Tensor] = None):
+    """dqkv; ``colsum`` (fp32 [3*H*D]) += the column sums of dqkv (query_key_value.bias gradient, mafed_attn_bwd_colsum)."""
     T = attention_mask.shape[1]
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
-    check(_lib.load().mafed_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _dt(qkv), B, S, H, D, rot, _ptr(cos), _ptr(sin),
-                                     _ptr(attention_mask), T, _ptr(dqkv), _ptr(delta), _stream()), "mafed_attn_bwd")
+    if colsum is None:
+        check(_lib.load().mafed_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _dt(qkv), B, S, H, D, rot, _ptr(cos), _ptr(sin),
+                                         _ptr(attention_mask), T, _ptr(dqkv), _ptr(delta), _stream()), "mafed_attn_bwd")
+    else:
+        assert colsum.dtype == torch.float32 and colsum.numel() == 3 * H * D and colsum.is_contiguous()
+        check(_lib.load().mafed_attn_bwd_colsum(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _dt(qkv), B, S, H, D, rot, _ptr(cos),
+                                                _ptr(sin), _ptr(attention_mask), T, _ptr(dqkv), _ptr(delta), _ptr(colsum), _stream()),
+              "mafed_attn_bwd_colsum")
     return dqkv
 
 

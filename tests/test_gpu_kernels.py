@@ -133,6 +133,30 @@ def test_gemm_split_k_accumulate(split):
     assert maxerr(out, ref) == 0.0
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 128, "none"), (288, 128, 64, "gelu_bwd"), (3072, 4096, 64, "gelu_bwd"), (576, 512, 192, "none"),
+                                        (100, 72, 40, "none")])
+def test_gemm_fused_colsum(dt, M, N, K, epi):
+    """mafed_gemm_colsum: colsum += column sums of the stored C, for every tile configuration with a fused epilogue
+    (128x128, 144x128, 192x128), the GELU' epilogue that feeds dense_h_to_4h.bias, and the second-pass route."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(dt).to(DEV)
+    Bm = torch.randn(K, N, generator=g).to(dt).to(DEV)
+    kw = {}
+    if epi == "gelu_bwd":
+        kw = dict(epilogue=ops.EPI_GELU_BWD, aux=torch.randn(M, N, generator=g).to(dt).to(DEV))
+    ref = ops.gemm(A, Bm, False, False, **kw)
+    cs = torch.full((N,), -1.25, dtype=torch.float32, device=DEV)
+    out = ops.gemm(A, Bm, False, False, colsum=cs, **kw)
+    assert torch.equal(out, ref)
+    want = out.double().sum(0) - 1.25
+    # bf16: the fused sums see the fp32 values before the store rounds them (each element moves by <= 2^-9 relative)
+    bound = out.double().abs().sum(0).max().item() * (1e-5 if dt == torch.float32 else 2.0 ** -8) + 1e-4
+    err = (cs.double() - want).abs().max().item()
+    assert err <= bound, (err, bound)
+
+
 def test_gemm_rejects_bad_arguments():
     ops = _ops()
     from mafed_amd._lib import MafedHipError
@@ -275,6 +299,9 @@ def test_attention_f32(B, P, T, H, D):
     assert_close(out.view(B, S, H * D), ref, 2e-5, "attn out")
     dqkv = ops.attn_bwd(dv(qkv).view(B * S, -1), out, dv(dout).view(B * S, -1), lse, B, S, H, D, rot, dv(cos), dv(sin), dv(am))
     assert_close(dqkv.view(B, S, H, 3, D), qd.grad, 5e-5, "attn dqkv")
+    csum = torch.zeros(3 * H * D, dtype=torch.float32, device=DEV)
+    ops.attn_bwd(dv(qkv).view(B * S, -1), out, dv(dout).view(B * S, -1), lse, B, S, H, D, rot, dv(cos), dv(sin), dv(am), colsum=csum)
+    assert_close(csum, qd.grad.reshape(B * S, -1).sum(0), 1e-4, "attn dqkv colsum (f32)")
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -307,7 +334,14 @@ def _attention_bf16_case(ops, B, P, T, H, D):
     # exact kernel on the same bf16 data agrees with the MFMA kernel on the log-sum-exp
     out_e, lse_e = ops.attn_fwd_exact_bf16(qg, B, S, H, D, rot, dv(cos), dv(sin), dv(am))
     assert_close(lse, lse_e, 2e-2, "lse")
-    dqkv = ops.attn_bwd(qg, out, dv(db).view(B * S, -1), lse, B, S, H, D, rot, dv(cos), dv(sin), dv(am))
+    csum = torch.full((3 * H * D,), 0.5, dtype=torch.float32, device=DEV)  # accumulate-into semantics: starts non-zero
+    dqkv = ops.attn_bwd(qg, out, dv(db).view(B * S, -1), lse, B, S, H, D, rot, dv(cos), dv(sin), dv(am), colsum=csum)
+    # fused query_key_value.bias gradient = column sums of dqkv (the kernels sum before the bf16 rounding of the store)
+    want = dqkv.float().sum(0) + 0.5
+    cerr = (csum - want).abs().max().item()
+    assert cerr <= dqkv.float().abs().sum(0).max().item() * 2.0 ** -8 + 1e-3, f"attn dqkv colsum err {cerr}"
+    dqkv2 = ops.attn_bwd(qg, out, dv(db).view(B * S, -1), lse, B, S, H, D, rot, dv(cos), dv(sin), dv(am))
+    assert torch.equal(dqkv, dqkv2), "the colsum entry point must not change dqkv"
     g = qd.grad
     err = (dqkv.float().view(B, S, H, 3, D).cpu().double() - g).abs().max().item()
     assert err <= 4e-2 * max(1.0, g.abs().max().item()), f"attn dqkv bf16 err {err} (scale {g.abs().max().item()})"
