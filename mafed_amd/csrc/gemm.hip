@@ -16,7 +16,7 @@
 #include "gemm_epilogue.h"
 
 #ifndef MAFED_GEMM_SPREAD_DMA
-#define MAFED_GEMM_SPREAD_DMA 0  // measured: spreading the DMA pieces between MFMA rows is 1.6x SLOWER (fc1 112 -> 180 us) -- the burst stays
+#define MAFED_GEMM_SPREAD_DMA 0  // measured twice (also with a hand-ordered, fence-pinned row schedule): a DMA piece between MFMA rows is 1.1-1.6x SLOWER than the burst (fc1 114 -> 177 us)
 #endif
 
 namespace mafed {
@@ -263,6 +263,20 @@ __device__ __forceinline__ bf16x8 glds_read_frag(const char* __restrict__ img, i
   }
 }
 
+#ifdef MAFED_GEMM_TRACE
+// Tuning builds only (tools/gemm_trace.py): per-block phase timestamps {hw_id, xcc_id, start, first tile landed, loop end,
+// block end} on the 100 MHz s_memrealtime clock, to see how the blocks that share a CU line up in time.
+__device__ unsigned long long* g_gemm_trace = nullptr;
+extern "C" int mafed_gemm_set_trace(void* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define MAFED_TRACE_MARK(slot) \
+  do { if (g_gemm_trace && threadIdx.x == 0 && blockIdx.y == 0) g_gemm_trace[(int64_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MAFED_TRACE_MARK(slot) do { } while (0)
+#endif
+
 // ABL (tuning only): 0 = real kernel; 1 = no DMA inside the loop; 2 = no MFMAs (fragments kept live); 3 = no fragment reads
 template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
@@ -302,6 +316,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
     tile_n = within / gm;
   }
   const int64_t m0 = (int64_t)tile_m * TM, n0 = (int64_t)tile_n * TN;
+#ifdef MAFED_GEMM_TRACE
+  if (g_gemm_trace && threadIdx.x == 0 && blockIdx.y == 0) {
+    g_gemm_trace[(int64_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    g_gemm_trace[(int64_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+  }
+  MAFED_TRACE_MARK(2);
+#endif
 
   // per-lane DMA sources (piece j = wave + i * NW); k-tile advance is +64 elements (KC) or +64 rows (KS)
   const bf16_t* asrc[A_PER_WAVE];
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     if (ABL != 6) __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
+    if (kt == 0) MAFED_TRACE_MARK(3);
     const bool more = kt + 1 < nkt;
     if (!SPREAD && ABL != 1 && ABL != 5 && ABL != 6 && more) issue((kt + 1) & 1, kt + 1);
     const char* sa = smem + (kt & 1) * STAGE;
@@ -395,6 +417,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
     }
   }
+  MAFED_TRACE_MARK(4);
   if (ABL == 4 || ABL == 5 || ABL == 6) {  // timing only: no C traffic (one element per wave keeps the accumulators live)
     float sacc = 0.f;
 #pragma unroll
@@ -557,6 +580,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
     }
   }
+  MAFED_TRACE_MARK(5);
 }
 
 static int g_gemm_group_m = 4;  // row-tiles per L2 patch of the grouped tile order (tuning: variant 300 + g)

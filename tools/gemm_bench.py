@@ -28,6 +28,9 @@ EPI = os.environ.get("GEMM_BENCH_EPI", "0") == "1"   # fc1 with bias + GELU + sa
 LIBREF = os.environ.get("GEMM_BENCH_LIB", "0") == "1"  # add a torch.matmul (hipBLASLt/rocBLAS) column as a yardstick
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
 lib = _lib.load()
+for pv in os.environ.get("GEMM_BENCH_PRE", "").split(","):
+    if pv:
+        lib.mafed_gemm_set_variant(int(pv))   # persistent knobs (split / group / desync ...), applied before the sweep
 g = torch.Generator(device=dev).manual_seed(0)
 res = {}
 for name, tA, tB, m, n, k, od in SHAPES:
