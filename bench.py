@@ -186,7 +186,19 @@ def main():
         for i in range(2):
             tr.step(task_batch, args.warmup + args.steps + i)
         torch.cuda.synchronize()
+        ev_overlapped, ops.GEMM_EVENTS = ops.GEMM_EVENTS, []
+        # ... and two steps with the side streams switched off (dW GEMMs and the teacher forward in line on the main
+        # stream): every GEMM then has the chip to itself, which is the number a per-kernel roofline should be read against
+        ov = (student.overlap_param_grads, fd.overlap_teacher)
+        student.overlap_param_grads, fd.overlap_teacher = False, False
+        for i in range(2):
+            tr.step(task_batch, args.warmup + args.steps + 2 + i)
+        torch.cuda.synchronize()
+        student.overlap_param_grads, fd.overlap_teacher = ov
+        ev_alone, ops.GEMM_EVENTS = ops.GEMM_EVENTS, ev_overlapped
         tr.use_graphs = graphs_on
+    else:
+        ev_alone = None
     if rank == 0:
         samples = args.steps * B * world
         value = samples / dt
@@ -208,6 +220,12 @@ def main():
                     "traffic": traffic, "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch of 2 more steps run right after the timed region)",
                     "launches": len(ev), "avg_launch_us": round(ms * 1e3 / len(ev), 2), "avg_gflop_per_launch": round(fl / len(ev) / 1e9, 3),
                     "note": "launch durations overlap: dW GEMMs and the teacher forward run on side streams"}
+            if ev_alone:
+                ms1 = sum(a.elapsed_time(b) for a, b, _ in ev_alone)
+                ach1 = sum(f for _, _, f in ev_alone) / (ms1 * 1e-3) / 1e12
+                roof["achieved_no_overlap"] = round(ach1, 2)
+                roof["frac_no_overlap"] = round(ach1 / PEAK_BF16_TFLOPS, 4)
+                roof["avg_launch_us_no_overlap"] = round(ms1 * 1e3 / len(ev_alone), 2)
         out = {"metric": "train samples/sec VLPythia-410M+MAFED, 256img+32txt tok, bs=32, 1/2/4/8 GPU" if args.model == "410m" else
                f"train samples/sec VLPythia-{args.model}+MAFED", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
