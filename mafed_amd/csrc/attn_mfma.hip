@@ -9,6 +9,8 @@
 // Partial rotary is applied while q / k rows are staged (on load), its transpose while dq / dk are stored.
 // Masking: fully causal over S = P + T, key padding from attention_mask (left-padded text); only tiles that touch the
 // diagonal or the text range pay for the mask.
+#include <type_traits>
+
 #include "attn.h"
 
 namespace mafed {
@@ -597,7 +599,7 @@ __device__ __forceinline__ int snake4(int w, int t) { return t * 4 + ((t & 1) ? 
 #define MAFED_LN2 0.6931471805599453f
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
                                                            const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -615,8 +617,14 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restr
   const bf16_t* vb = qb + 2 * D;
   const int nslices = (S + 15) / 16;
   const int hc = rot >> 4, items = S * hc;
+#if defined(MAFED_ATTN_ABL) && MAFED_ATTN_ABL == 3
+  if (tid == 0) out[((int64_t)b * S) * H * D + (int64_t)h * D] = 0;
+  return;
+#endif
   dma_rows<D>(kimg, kb, rstride, nrows, S, wave, lane);
+#if !defined(MAFED_ATTN_ABL) || MAFED_ATTN_ABL != 4
   dma_rows<D>(vimg, vb, rstride, nrows, S, wave, lane);
+#endif
   RotPre pre[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restr
   __syncthreads();
   rot_fix_rows<D>(kimg, items, hc, rot, rc, rs, pre, tid);
   __syncthreads();
-#if defined(MAFED_ATTN_ABL) && MAFED_ATTN_ABL == 1
+#if defined(MAFED_ATTN_ABL) && (MAFED_ATTN_ABL == 1 || MAFED_ATTN_ABL == 4)
   if (tid < 64) out[((int64_t)b * S + tid) * H * D + (int64_t)h * D] = *reinterpret_cast<const bf16_t*>(kimg + tid * 1024) + *reinterpret_cast<const bf16_t*>(vimg + tid * 1024);
   return;
 #endif
@@ -653,21 +661,22 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restr
     for (int i = 0; i < D / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const int last_kt = (q0 + 15) / 64;
-    for (int kt = 0; kt <= last_kt; ++kt) {
-      const int nj = kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4;  // 16-key sub-tiles with a key <= q0 + 15
+    // one 64-key tile; MASK = false for tiles that lie wholly below the diagonal and wholly inside the image keys (most of
+    // them): no bias read, no compares.  nj = 16-key sub-tiles with a key <= q0 + 15.
+    auto tile = [&](const int kt, const int nj, auto mask_tag) {
+      constexpr bool MASK = decltype(mask_tag)::value;
       f32x4 s[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j < nj) {
+        if (!MASK || j < nj) {
 #pragma unroll
           for (int ks = 0; ks < D / 32; ++ks)
             s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s[j], 0, 0, 0);
         }
       }
-      const bool need_mask = (kt == last_kt) || (kt * 64 + 63 >= P);
       float tmax = -INFINITY;
-      if (need_mask) {
+      if (MASK) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j < nj) {
@@ -696,31 +705,40 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restr
           }
       }
       tmax = col_max_sw(tmax);
-      const float mn = fmaxf(m, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
-      m = mn;
+      // Lazy rescale: the running reference m only moves when some row's maximum outgrew it by more than 2^8 (exact
+      // arithmetic either way -- p and l are scaled by the same 2^(m_true - m)); the output accumulators are then touched
+      // by the VALU a couple of times per slice instead of once per tile.
+      if (__builtin_amdgcn_ballot_w64(tmax - m > 8.0f) != 0) {
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) o[i] *= alpha;
+      }
       float ps = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[j][r] - mn);
+          const float pv = __builtin_amdgcn_exp2f(s[j][r] - m);
           s[j][r] = pv;
           ps += pv;
         }
-      l = l * alpha + ps;
-#pragma unroll
-      for (int i = 0; i < D / 16; ++i) o[i] *= alpha;
+      l += ps;
       const bf16x8 p0 = pack_acc(s[0], s[1]);
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2, lane), p0, o[dt], 0, 0, 0);
-      if (nj > 2) {
+      if (!MASK || nj > 2) {
         const bf16x8 p1 = pack_acc(s[2], s[3]);
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2 + 1, lane), p1, o[dt], 0, 0, 0);
       }
-    }
+    };
+    const int kt_plain = last_kt < P / 64 ? last_kt : P / 64;  // tiles [0, kt_plain): every key < P and < q0
+    for (int kt = 0; kt < kt_plain; ++kt) tile(kt, 4, std::false_type{});
+    for (int kt = kt_plain; kt <= last_kt; ++kt) tile(kt, kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4, std::true_type{});
     l = col_sum_sw(l);
     if (myq < S) {
       const float inv = 1.0f / l;
@@ -734,7 +752,7 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const bf16_t* __restr
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse, AttnShape sh,
                                                               const float* __restrict__ rc, const float* __restrict__ rs,
                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
@@ -745,12 +763,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
   const int nrows = (S + 31) / 32 * 32;
-  f32x4 bs[D / 16];  // running column sums of the stored dq rows (query_key_value.bias gradient), when asked for
-#pragma unroll
-  for (int i = 0; i < D / 16; ++i) bs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   char* kimg = lds;
   char* vimg = lds + nrows * D * 2;
   float* kbias = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
+  float* red = kbias + 2 * nrows;  // [D] column sums of the stored dq rows (query_key_value.bias gradient), when asked for
+  if (bsum && tid < D) red[tid] = 0.f;
   const int64_t rstride = (int64_t)H * 3 * D;
   const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
   const bf16_t* kb = qb + D;
@@ -819,21 +836,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int last_kt = (q0 + 15) / 64;
-    for (int kt = 0; kt <= last_kt; ++kt) {
-      const int nj = kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4;
-      const bool need_mask = (kt == last_kt) || (kt * 64 + 63 >= P);
+    auto tile = [&](const int kt, const int nj, auto mask_tag) {
+      constexpr bool MASK = decltype(mask_tag)::value;
       f32x4 ds[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ds[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j < nj) {
+        if (!MASK || j < nj) {
           f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < D / 32; ++ks) {
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(kimg, kt * 4 + j, ks, lane), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(vimg, kt * 4 + j, ks, lane), dof[ks], dp, 0, 0, 0);
           }
-          if (need_mask) {
+          if (MASK) {
             const float4 kb4 = *reinterpret_cast<const float4*>(kbias + kt * 64 + j * 16 + 4 * g);
             const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
 #pragma unroll
@@ -852,32 +868,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_res_kernel(const bf16_t* __re
       const bf16x8 d0 = pack_acc(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2, lane), d0, dq[dt], 0, 0, 0);
-      if (nj > 2) {
+      if (!MASK || nj > 2) {
         const bf16x8 d1 = pack_acc(ds[2], ds[3]);
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt)
           dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(kimg, dt, kt * 2 + 1, lane), d1, dq[dt], 0, 0, 0);
       }
-    }
+    };
+    const int kt_plain = last_kt < P / 64 ? last_kt : P / 64;
+    for (int kt = 0; kt < kt_plain; ++kt) tile(kt, 4, std::false_type{});
+    for (int kt = kt_plain; kt <= last_kt; ++kt) tile(kt, kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4, std::true_type{});
     bf16_t* dqp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)myq * rstride;
     store_grad_unrot<D>(dqp, dq, rot, rc, rs, myq, lane, myq < S);
-    if (bsum && myq < S) {
+    if (bsum) {  // fold the slice's 16 queries (one DPP row), accumulate in LDS: no registers live across slices
 #pragma unroll
-      for (int i = 0; i < D / 16; ++i) bs[i] += dq[i];
+      for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = row16_sum(myq < S ? dq[dt][r] : 0.f);
+          if ((lane & 15) == 0) atomicAdd(red + dt * 16 + 4 * g + r, v);
+        }
     }
   }
-  if (bsum) {  // fold the 16 queries of a lane row, then the four waves, then one 4*D-byte run of atomics per block
+  if (bsum) {  // one 4*D-byte run of atomics per block
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = row16_sum(bs[dt][r]);
-        if ((lane & 15) == 0) red[wave * D + dt * 16 + 4 * (lane >> 4) + r] = v;
-      }
-    __syncthreads();
-    if (tid < D) atomicAdd(bsum + (int64_t)h * 3 * D + tid, red[tid] + red[D + tid] + red[2 * D + tid] + red[3 * D + tid]);
+    if (tid < D) atomicAdd(bsum + (int64_t)h * 3 * D + tid, red[tid]);
   }
 }
 
@@ -896,13 +911,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
   const int h = blockIdx.x, b = blockIdx.y;
   const int nrows = (S + 31) / 32 * 32;
-  f32x4 bsk[D / 16], bsv[D / 16];
-#pragma unroll
-  for (int i = 0; i < D / 16; ++i) { bsk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; bsv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   char* qimg = lds;
   char* doimg = lds + nrows * D * 2;
   float* L2s = reinterpret_cast<float*>(lds + 2 * nrows * D * 2);
   float* Ds = L2s + nrows;
+  float* red = Ds + nrows;  // [dk D | dv D] column sums of the stored rows, when asked for
+  if (bsum && tid < 2 * D) red[tid] = 0.f;
   const int64_t rstride = (int64_t)H * 3 * D;
   const bf16_t* qb = qkv + ((int64_t)b * S * H + h) * 3 * D;
   const bf16_t* kb = qb + D;
@@ -960,16 +974,16 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
     for (int i = 0; i < D / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int qt0 = k0 / 64;
     const bool text_keys = k0 + 15 >= P;
-    for (int qt = qt0; qt < nqt; ++qt) {
-      const int jlo = qt == qt0 ? (k0 - qt * 64) >> 4 : 0;           // query sub-tiles entirely before the slice's keys are skipped
-      const int jhi = (nrows - qt * 64) >> 4 < 4 ? (nrows - qt * 64) >> 4 : 4;
-      const bool need_mask = (qt == qt0) || text_keys;
+    // one 64-query tile; EDGE = the diagonal tile, the ragged last tile, or any tile of a slice that holds text keys
+    // (sub-tile skipping + causal / padding select); plain tiles below the diagonal need neither
+    auto tile = [&](const int qt, const int jlo, const int jhi, auto edge_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
       f32x4 p[4], ds[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         p[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ds[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j >= jlo && j < jhi) {
+        if (!EDGE || (j >= jlo && j < jhi)) {
           f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < D / 32; ++ks) {
@@ -982,7 +996,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = s[r] * scale2 - Lv[r];
-            if (need_mask) {
+            if (EDGE) {
               const int q = qt * 64 + j * 16 + 4 * g + r;
               x = mykey_eff > q ? -INFINITY : x;
             }
@@ -992,7 +1006,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
           }
         }
       }
-      if (jlo < 2) {
+      if (!EDGE || jlo < 2) {
         const bf16x8 p0 = pack_acc(p[0], p[1]), d0 = pack_acc(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
@@ -1000,7 +1014,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
           dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2, lane), d0, dk[dt], 0, 0, 0);
         }
       }
-      if (jhi > 2) {
+      if (!EDGE || jhi > 2) {
         const bf16x8 p1 = pack_acc(p[2], p[3]), d1 = pack_acc(ds[2], ds[3]);
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
@@ -1008,6 +1022,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
           dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(qimg, dt, qt * 2 + 1, lane), d1, dk[dt], 0, 0, 0);
         }
       }
+    };
+    const int nfull = nrows / 64;  // tiles [0, nfull) have all four query sub-tiles inside the image
+    for (int qt = qt0; qt < nqt; ++qt) {
+      const int jlo = qt == qt0 ? (k0 - qt * 64) >> 4 : 0;           // query sub-tiles entirely before the slice's keys are skipped
+      const int jhi = (nrows - qt * 64) >> 4 < 4 ? (nrows - qt * 64) >> 4 : 4;
+      if (qt == qt0 || text_keys || qt >= nfull) tile(qt, jlo, jhi, std::true_type{});
+      else tile(qt, 0, 4, std::false_type{});
     }
     bf16_t* dkp = dqkv + ((int64_t)b * S * H + h) * 3 * D + (int64_t)mykey * rstride + D;
     store_grad_unrot<D>(dkp, dk, rot, rc, rs, mykey, lane, mykey < S);
@@ -1015,33 +1036,29 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
       bf16_t* dvp = dkp + D;
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) store4(dvp + dt * 16 + 4 * g, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
-      if (bsum) {
+    }
+    if (bsum) {
 #pragma unroll
-        for (int i = 0; i < D / 16; ++i) { bsk[i] += dk[i]; bsv[i] += dv[i]; }
-      }
+      for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vk = row16_sum(mykey < S ? dk[dt][r] : 0.f), vv = row16_sum(mykey < S ? dv[dt][r] : 0.f);
+          if ((lane & 15) == 0) {
+            atomicAdd(red + dt * 16 + 4 * g + r, vk);
+            atomicAdd(red + D + dt * 16 + 4 * g + r, vv);
+          }
+        }
     }
   }
   if (bsum) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);  // [4 waves][dk D | dv D]
-#pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float vk = row16_sum(bsk[dt][r]), vv = row16_sum(bsv[dt][r]);
-        if ((lane & 15) == 0) {
-          red[wave * 2 * D + dt * 16 + 4 * (lane >> 4) + r] = vk;
-          red[wave * 2 * D + D + dt * 16 + 4 * (lane >> 4) + r] = vv;
-        }
-      }
-    __syncthreads();
-    if (tid < 2 * D) atomicAdd(bsum + (int64_t)h * 3 * D + D + tid, red[tid] + red[2 * D + tid] + red[4 * D + tid] + red[6 * D + tid]);
+    if (tid < 2 * D) atomicAdd(bsum + (int64_t)h * 3 * D + D + tid, red[tid]);
   }
 }
 
 static bool attn_resident_fits(const AttnShape& sh, size_t* bytes) {
   const size_t nrows = (size_t)(sh.S + 31) / 32 * 32;
-  *bytes = nrows * sh.D * 2 * 2 + nrows * 4 * 2;  // two operand images + two fp32 rows (key bias | LSE, delta)
+  *bytes = nrows * sh.D * 2 * 2 + nrows * 4 * 2 + (size_t)sh.D * 4 * 2;  // two operand images + two fp32 rows (key bias | LSE, delta) + the column-sum row
   return *bytes <= 160 * 1024;
 }
 static int g_attn_variant = 0;  // 0 automatic, 1 force the tiled kernels (tests)

@@ -92,6 +92,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
   for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
     const float mu = mean[row], rs = rstd[row];
     float4 xh[NV], g[NV];
+    // the residual-path gradient and the teacher row are only consumed after the two row reductions: fetch them now, with
+    // the first phase's loads, so that their latency hides behind the reductions instead of following them
+    float4 rres[NV], rte[NV];
+    float inj = 0.f;
+    if (teacher) {
+      const int cls = modality_class(row, S, P, T, attention_mask);
+      inj = cls == 0 ? ls : (cls == 1 ? vs : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      rres[i] = (dres && c < h) ? load4(dres + row * h + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rte[i] = (teacher && c < h) ? load4(teacher + row * h + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -116,26 +130,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
       }
     }
     const float mg = wave_sum(sg) / (float)h, mgx = wave_sum(sgx) / (float)h;
-    float inj = 0.f;
-    if (teacher) {
-      const int cls = modality_class(row, S, P, T, attention_mask);
-      inj = cls == 0 ? ls : (cls == 1 ? vs : 0.f);
-    }
+    const float istd = 1.0f / rs;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < h) {
         float4 o = make_float4(rs * (g[i].x - mg - xh[i].x * mgx), rs * (g[i].y - mg - xh[i].y * mgx),
                                rs * (g[i].z - mg - xh[i].z * mgx), rs * (g[i].w - mg - xh[i].w * mgx));
-        if (dres) {
-          const float4 r = load4(dres + row * h + c);
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        if (dres) { o.x += rres[i].x; o.y += rres[i].y; o.z += rres[i].z; o.w += rres[i].w; }
         if (teacher && inj != 0.f) {
-          const float4 tv = load4(teacher + row * h + c);
-          const float4 xv = load4(x + row * h + c);  // L1/L2 hit: the row was read above
-          o.x += inj * (xv.x - tv.x); o.y += inj * (xv.y - tv.y);
-          o.z += inj * (xv.z - tv.z); o.w += inj * (xv.w - tv.w);
+          // x = mu + xh / rstd (the row itself is no longer in registers)
+          const float4 tv = rte[i];
+          o.x += inj * (mu + xh[i].x * istd - tv.x); o.y += inj * (mu + xh[i].y * istd - tv.y);
+          o.z += inj * (mu + xh[i].z * istd - tv.z); o.w += inj * (mu + xh[i].w * istd - tv.w);
         }
         store4(dx + row * h + c, o);
         if (dx_lp) store4(dx_lp + row * h + c, o);
