@@ -38,7 +38,7 @@ with open(out + "/bench_kernel_by_shape.csv", "w") as g:
     for (n, wg), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
         g.write('"%s",%d,%d,%.1f,%.2f\n' % (n, wg, c, t / c / 1e3, t / 1e6))
 PY
-python3 tools/trace_timeline.py "$kt" 3 > $OUT/timeline.txt
+python3 tools/trace_timeline.py "$kt" 8 > $OUT/timeline.txt
 rm -rf gpurun_out/prof_kt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/prof_$c
