@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
                                                             const int64_t* __restrict__ attention_mask, int S, int P, int T,
                                                             const float* __restrict__ inj_scale, float inj_mul,
                                                             float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [3 waves][NP][h] staging for the cross-wave sum
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [3 waves][h] staging for the cross-wave sum
   constexpr int NP = (DUAL ? 4 : 2) + (DXSUM ? 1 : 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 aw1[NV], ab1[NV], aw2[DUAL ? NV : 1], ab2[DUAL ? NV : 1], adx[DXSUM ? NV : 1];
@@ -150,50 +150,43 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
       }
     }
   }
-  // cross-wave sum of the parameter partials: waves 1..3 stage to LDS, wave 0 adds and writes the block's slab
-  float* stage = lds + (size_t)(wave > 0 ? wave - 1 : 0) * NP * h;
-  if (wave > 0) {
+  // cross-wave sum of the parameter partials, one array at a time: waves 1..3 stage it to LDS ([3][h] floats = 12 KiB at
+  // h = 1024), wave 0 adds and writes the block's slab.  Staging all NP arrays at once needed 60 KiB of LDS, which kept
+  // these blocks off every CU that already held two GEMM blocks; at 12 KiB they slot in beside the weight-gradient GEMMs
+  // of the side streams (HBM-bound work under MFMA-bound work).
+  float* out = partial + (size_t)blockIdx.x * NP * h;
+  auto fold = [&](float4 (&acc)[NV], int slot) {
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < h) {
-        store4(stage + 0 * h + c, aw1[i]);
-        store4(stage + 1 * h + c, ab1[i]);
-        if (DUAL) { store4(stage + 2 * h + c, aw2[i]); store4(stage + 3 * h + c, ab2[i]); }
-        if (DXSUM) store4(stage + (NP - 1) * h + c, adx[i]);
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < h) store4(lds + (size_t)(wave - 1) * h + c, acc[i]);
       }
     }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* out = partial + (size_t)blockIdx.x * NP * h;
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < h) {
-        float4 a = aw1[i], b = ab1[i], c2 = DUAL ? aw2[i] : a, d = DUAL ? ab2[i] : b, e = DXSUM ? adx[i] : a;
-        for (int w = 0; w < 3; ++w) {
-          const float* st = lds + (size_t)w * NP * h;
-          float4 t0 = load4(st + 0 * h + c), t1 = load4(st + 1 * h + c);
-          a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
-          b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
-          if (DXSUM) {
-            float4 t4 = load4(st + (NP - 1) * h + c);
-            e.x += t4.x; e.y += t4.y; e.z += t4.z; e.w += t4.w;
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < h) {
+          float4 a = acc[i];
+          for (int w = 0; w < 3; ++w) {
+            const float4 t = load4(lds + (size_t)w * h + c);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
           }
-          if (DUAL) {
-            float4 t2 = load4(st + 2 * h + c), t3 = load4(st + 3 * h + c);
-            c2.x += t2.x; c2.y += t2.y; c2.z += t2.z; c2.w += t2.w;
-            d.x += t3.x; d.y += t3.y; d.z += t3.z; d.w += t3.w;
-          }
+          store4(out + (size_t)slot * h + c, a);
         }
-        store4(out + 0 * h + c, a);
-        store4(out + 1 * h + c, b);
-        if (DUAL) { store4(out + 2 * h + c, c2); store4(out + 3 * h + c, d); }
-        if (DXSUM) store4(out + (NP - 1) * h + c, e);
       }
     }
+    __syncthreads();
+  };
+  fold(aw1, 0);
+  fold(ab1, 1);
+  if constexpr (DUAL) {
+    fold(aw2, 2);
+    fold(ab2, 3);
   }
+  if constexpr (DXSUM) fold(adx, NP - 1);
 }
 
 // out_k[c] += sum_b partial[b][k][c]   (k = 0..NP-1 -> dw1, db1, dw2, db2); 64 columns x 4 slab groups per block
@@ -308,7 +301,7 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
     set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, (size_t)nblk * np * h * sizeof(float));
     return MAFED_EWORKSPACE;
   }
-  const size_t lds_bytes = (size_t)3 * np * h * sizeof(float);
+  const size_t lds_bytes = (size_t)3 * h * sizeof(float);
   MAFED_CHECK_ARG(lds_bytes <= 160 * 1024, "layernorm_bwd: LDS staging %zu too large", lds_bytes);
   hipStream_t st = as_stream(stream);
   float* partial = (float*)workspace;
