@@ -126,6 +126,18 @@ int mafed_attn_bwd_colsum(const void* qkv, const void* out, const void* dout, co
                           int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                           const int64_t* attention_mask, int T, void* dqkv, float* delta, float* dqkv_colsum, void* stream);
 
+/* ---- online EWC penalty (mafed/methods/ewc.py:105-127) -------------------------------------
+ * The reference's compute_regularization over named_parameters(), on the flat fp32 buffers:
+ *   fwd: out[0] = beta * out[0] + half_lambda * sum_i fisher[i] * (p[i] - p_old[i])^2     (half_lambda = 0.5 * reg_lambda;
+ *        beta = 1 chains the per-task terms of the non-online variant, ewc.py:124-126)
+ *   bwd: grad[i] += coef_dev[0] * lambda * fisher[i] * (p[i] - p_old[i])                  (coef_dev = d loss / d penalty)
+ * Deterministic two-stage reduction; workspace from mafed_ewc_workspace_bytes. */
+size_t mafed_ewc_workspace_bytes(int64_t n);
+int mafed_ewc_penalty_fwd(const float* p, const float* p_old, const float* fisher, int64_t n, float half_lambda, float beta,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream);
+int mafed_ewc_penalty_bwd(const float* p, const float* p_old, const float* fisher, int64_t n, float lambda,
+                          const float* coef_dev, float* grad, void* stream);
+
 /* ---- embedding + concat (mafed/model/vl_pythia.py:282-283) ---------------------------------------------------
  * h0[b, :P] = image[b] ; h0[b, P:] = embed_in[input_ids[b]]  -> fp32 [B,P+T,h].  image in img_dtype [B,P,h]. */
 int mafed_embed_concat_fwd(const void* image, mafed_dtype img_dtype, const float* embed_in, const int64_t* input_ids,

@@ -7,7 +7,7 @@ hand-written HIP kernels behind the C-ABI of ``include/mafed_hip.h`` (``libmafed
 """
 __version__ = "0.1.0"
 
-from mafed_amd.methods import CLMethod, CLStrategy, ER, FeatureDistillation, Naive  # noqa: F401
+from mafed_amd.methods import CLMethod, CLStrategy, ER, EWC, FeatureDistillation, Naive  # noqa: F401
 from mafed_amd.model import VLPythiaConfig, VLPythiaForCausalLM, model_architecture  # noqa: F401
 from mafed_amd.optim import FlatAdamW, get_linear_schedule_with_warmup  # noqa: F401
 from mafed_amd.trainer import Trainer  # noqa: F401

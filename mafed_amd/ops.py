@@ -259,6 +259,26 @@ def distill_cls_bwd(s, t, coef) -> torch.Tensor:
     return out
 
 
+def ewc_penalty_fwd(p: torch.Tensor, p_old: torch.Tensor, fisher: torch.Tensor, half_lambda: float,
+                    out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """out[0] = beta * out[0] + half_lambda * sum fisher * (p - p_old)^2 over flat fp32 buffers."""
+    assert p.dtype == torch.float32 and p.is_contiguous() and p_old.shape == p.shape and fisher.shape == p.shape
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=p.device)
+    ws = workspace(p.device).get(lib.mafed_ewc_workspace_bytes(p.numel()))
+    check(lib.mafed_ewc_penalty_fwd(_ptr(p), _ptr(p_old), _ptr(fisher), p.numel(), float(half_lambda), float(beta), _ptr(out), _ptr(ws),
+                                    ws.numel(), _stream()), "mafed_ewc_penalty_fwd")
+    return out
+
+
+def ewc_penalty_bwd_(p: torch.Tensor, p_old: torch.Tensor, fisher: torch.Tensor, lam: float, coef: torch.Tensor, grad: torch.Tensor) -> None:
+    """grad += coef[0] * lam * fisher * (p - p_old)"""
+    assert grad.dtype == torch.float32 and grad.shape == p.shape and coef.dtype == torch.float32
+    check(_lib.load().mafed_ewc_penalty_bwd(_ptr(p), _ptr(p_old), _ptr(fisher), p.numel(), float(lam), _ptr(coef), _ptr(grad), _stream()),
+          "mafed_ewc_penalty_bwd")
+
+
 def gradnorm_clip(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> out[2] = {||g||, clip scale}"""
     lib = _lib.load()

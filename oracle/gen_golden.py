@@ -386,6 +386,82 @@ def gen_optim_fixture(refs):
     print("optim fixture ok")
 
 
+def gen_ewc_fixture(refs, name="t64", seed=21, reg_lambda=10000.0):
+    """the reference's own ``EWC`` (mafed/methods/ewc.py) -- two between-task importance passes (the
+    second exercising the online decay), the per-step quadratic penalty and the gradient of CE + penalty."""
+    from mafed.methods.ewc import EWC
+    import mafed.methods.ewc as ewc_mod
+    ewc_mod.tqdm = lambda it, **k: it
+    vp = refs[0]
+    cfg = tiny_cfg(name)
+    t = TINY[name]
+    sd0 = R.init_weights(cfg, seed=seed)
+    model = build_ref_model(vp, cfg, sd0)
+    names = [k for k, _ in R.param_shapes(cfg)]
+    loaders = [[ref_batch(R.make_batch(cfg, t["B"], t["T"], seed=seed + 10 * r + i, pad=True)) for i in range(2)] for r in range(2)]
+    ewc = EWC(reg_lambda=reg_lambda, online=True, online_factor=0.95)
+    out = {"reg_lambda": np.float64(reg_lambda), "online_factor": np.float64(0.95), "seed": np.int64(seed)}
+
+    def summarise(tag):
+        f = ewc.fisher[0]
+        out[tag + "/sum"] = np.array([float(f[k].double().sum()) for k in names], np.float64)
+        out[tag + "/max"] = np.array([float(f[k].max()) for k in names], np.float64)
+        for k in ("gpt_neox.layers.0.input_layernorm.weight", "gpt_neox.layers.1.mlp.dense_4h_to_h.bias", "vision_embed_tokens.0.bias"):
+            out[tag + "/full/" + k] = np_(f[k])
+        out[tag + "/rows4/gpt_neox.layers.0.mlp.dense_h_to_4h.weight"] = np_(f["gpt_neox.layers.0.mlp.dense_h_to_4h.weight"][:4])
+
+    # task 0 -> 1: importances at sd0 (CPU bf16 autocast inside the reference, ewc.py:86)
+    ewc.update(model=model, dataloader=loaders[0])
+    summarise("fisher1")
+    assert ewc.task_id == 1
+    # "training" on task 1 = a deterministic perturbation; then one step's loss and gradient with the penalty
+    sd1 = R.perturb(sd0, seed=seed + 1, std=2e-3)
+    model.load_state_dict(sd1, strict=False)
+    batch = ref_batch(R.make_batch(cfg, t["B"], t["T"], seed=seed + 5, pad=True))
+    model.zero_grad()
+    ce = model(**batch, compute_loss=True, return_dict=True).loss
+    total = ewc.compute_loss(model, ce.clone())
+    total.backward()
+    out["step/ce"] = np.float64(float(ce.detach()))
+    out["step/total"] = np.float64(float(total.detach()))
+    _, norms, gtot, full = grads_summary(model, cfg)
+    out["step/grad_norms"] = norms
+    out["step/grad_total"] = np.float64(gtot)
+    for k, v in full.items():
+        out["step/" + k] = v
+    # the same step with a synthetic Fisher diagonal (|N(0, 0.02)| from the build's generator) installed in the reference
+    # object: pins compute_regularization and its gradient exactly, free of the bf16 noise of the importance pass
+    real_fisher = ewc.fisher[0]
+    syn = {k: v.abs() for k, v in R.init_weights(cfg, seed=seed + 7).items()}
+    ewc.fisher[0] = {k: syn[k].clone() for k in real_fisher}
+    model.zero_grad()
+    ce2 = model(**batch, compute_loss=True, return_dict=True).loss
+    total2 = ewc.compute_loss(model, ce2.clone())
+    total2.backward()
+    out["step_syn/ce"] = np.float64(float(ce2.detach()))
+    out["step_syn/total"] = np.float64(float(total2.detach()))
+    _, norms2, gtot2, full2 = grads_summary(model, cfg)
+    out["step_syn/grad_norms"] = norms2
+    out["step_syn/grad_total"] = np.float64(gtot2)
+    for k, v in full2.items():
+        out["step_syn/" + k] = v
+    ewc.fisher[0] = real_fisher
+    # task 1 -> 2: task_id is still 1 when update() runs, so the importances are overwritten (ewc.py:56-57); anchor := sd1
+    model.zero_grad()
+    ewc.update(model=model, dataloader=loaders[1])
+    summarise("fisher2")
+    assert ewc.task_id == 2
+    # task 2 -> 3: the online accumulation proper, fisher = new + 0.95 * old (ewc.py:58-61), at weights sd2
+    sd2 = R.perturb(sd1, seed=seed + 2, std=2e-3)
+    model.load_state_dict(sd2, strict=False)
+    model.zero_grad()
+    ewc.update(model=model, dataloader=loaders[0])
+    summarise("fisher3")
+    assert ewc.task_id == 3
+    np.savez_compressed(os.path.join(OUT, f"ewc_{name}.npz"), **out)
+    print("ewc fixture ok: ce %.5f total %.5f (synthetic Fisher: %.5f)" % (float(ce), float(total), float(total2)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import logging
@@ -399,6 +475,7 @@ def main():
         gen_model_fixture(name, refs)
     gen_trainer_fixture(refs)
     gen_optim_fixture(refs)
+    gen_ewc_fixture(refs)
 
 
 if __name__ == "__main__":

@@ -448,6 +448,44 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
         p.add_(p, alpha=-lr * wd)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Online EWC (mafed/methods/ewc.py)
+# ---------------------------------------------------------------------------------------------------------------
+def ewc_importances(sd: Dict[str, torch.Tensor], batches: Sequence[Dict[str, torch.Tensor]], cfg: RefConfig,
+                    autocast_bf16: bool = True) -> Dict[str, torch.Tensor]:
+    """compute_importances (ewc.py:70-103): Fisher diagonal = sum over batches of grad(B * CE)^2, divided by the number of
+    samples.  The reference runs the forward under bf16 autocast on whatever device it is on (ewc.py:84-86)."""
+    imp = {k: torch.zeros_like(v) for k, v in sd.items()}
+    total = 0.0
+    for batch in batches:
+        params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+        bsz = batch["input_ids"].size(0)
+        loss = bsz * forward(params, batch, cfg, autocast_bf16).loss
+        loss.backward()
+        for k in imp:
+            if params[k].grad is not None:
+                imp[k] += params[k].grad.detach().pow(2)
+        total += bsz
+    return {k: v / total for k, v in imp.items()}
+
+
+def ewc_online_update(old: Optional[Dict[str, torch.Tensor]], new: Dict[str, torch.Tensor], task_id: int,
+                      online_factor: float = 0.95) -> Dict[str, torch.Tensor]:
+    """update (ewc.py:52-62), online=True: the first two updates overwrite, later ones decay the running sum."""
+    if old is None or task_id <= 1:
+        return new
+    return {k: new[k] + online_factor * old[k] for k in new}
+
+
+def ewc_penalty(params: Dict[str, torch.Tensor], old_params: Dict[str, torch.Tensor], fisher: Dict[str, torch.Tensor],
+                reg_lambda: float) -> torch.Tensor:
+    """compute_regularization (ewc.py:105-115): sum over parameters of 0.5 * lambda * sum(F * (p - p*)^2)."""
+    loss = torch.zeros((), dtype=torch.float32)
+    for k, p in params.items():
+        loss = loss + 0.5 * reg_lambda * (fisher[k] * (p - old_params[k]).pow(2)).sum()
+    return loss
+
+
 @dataclass
 class RefTrainer:
     """Reproduces the Lightning automatic-optimisation order around VLPythiaVQACLearner.training_step

@@ -61,3 +61,18 @@ def g3_spec(vname, cfg, g):
     if kw["modality"] == "adaptive":
         kw["lang_coeff"] = torch.from_numpy(g["g3/adaptive_lang_coeff"])
     return R.DistillSpec(distillation_coeff=1.5, replay_coeff=0.7, **kw)
+
+
+def ewc_setup(name="t64"):
+    """Inputs of oracle/gen_golden.py::gen_ewc_fixture: (cfg, golden, anchor weights sd0, task-1 weights sd1, the two importance
+    loaders, the step batch, the synthetic Fisher diagonal)."""
+    g = load_golden(f"ewc_{name}.npz")
+    cfg = tiny_cfg(name)
+    t = TINY[name]
+    seed = int(g["seed"])
+    sd0 = R.init_weights(cfg, seed=seed)
+    loaders = [[R.make_batch(cfg, t["B"], t["T"], seed=seed + 10 * r + i, pad=True) for i in range(2)] for r in range(2)]
+    sd1 = R.perturb(sd0, seed=seed + 1, std=2e-3)
+    batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 5, pad=True)
+    syn = {k: v.abs() for k, v in R.init_weights(cfg, seed=seed + 7).items()}
+    return cfg, g, sd0, sd1, loaders, batch, syn

@@ -21,7 +21,7 @@ def small_model(device="cpu"):
 
 def test_registry_and_protocol():
     from mafed_amd import CLMethod, CLStrategy, ER, FeatureDistillation, Naive, model_architecture
-    assert set(CLMethod) == {"naive", "replay", "featdistill"}
+    assert set(CLMethod) == {"naive", "ewc", "replay", "featdistill"}   # the reference's registry (mafed/methods/__init__.py:6-11)
     assert CLMethod["featdistill"] is FeatureDistillation and CLMethod["replay"] is ER and CLMethod["naive"] is Naive
     assert "vlpythia" in model_architecture
     base = CLStrategy(opts=types.SimpleNamespace(accumulate_grad_batches=4))

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vlpythia_ref as R
-from tests.helpers import G3_VARIANTS, TINY, g3_spec, golden_setup, load_golden
+from tests.helpers import G3_VARIANTS, TINY, ewc_setup, g3_spec, golden_setup, load_golden
 
 TOL = 2e-5
 
@@ -132,3 +132,64 @@ def test_trainer_sequence():
     close([r["lr"] for r in tr.log if "lr" in r], g["seq/lr"], 1e-9)
     close([r["param_checksum"] for r in tr.log if "param_checksum" in r], g["seq/checksum"], 1e-6)
     close(tr.params["gpt_neox.final_layer_norm.weight"].detach().numpy(), g["final/gpt_neox.final_layer_norm.weight"], 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# online EWC against the reference's own EWC class
+# ---------------------------------------------------------------------------------------------------------------
+def _fisher_checks(f, g, tag, tol):
+    names = list(f)
+    close(np.array([float(f[k].double().sum()) for k in names]), g[tag + "/sum"], tol)
+    for key in g.files:
+        if key.startswith(tag + "/full/"):
+            close(f[key[len(tag) + 6:]].numpy(), g[key], tol)
+        elif key.startswith(tag + "/rows4/"):
+            close(f[key[len(tag) + 7:]][:4].numpy(), g[key], tol)
+
+
+def test_ewc_importances_and_online_update():
+    """The importance pass runs under CPU bf16 autocast inside the reference (ewc.py:84-86): the oracle follows it through
+    its own autocast forward, so agreement is at bf16 level (the two forwards round in slightly different places)."""
+    cfg, g, sd0, sd1, loaders, batch, syn = ewc_setup()
+    f1 = R.ewc_importances(sd0, loaders[0], cfg, autocast_bf16=True)
+    _fisher_checks(f1, g, "fisher1", 2e-2)
+    of = float(g["online_factor"])
+    f1 = R.ewc_online_update(None, f1, task_id=0, online_factor=of)
+    # second update: task_id is 1 when it runs -> overwritten, not accumulated (ewc.py:56-57)
+    f2 = R.ewc_online_update(f1, R.ewc_importances(sd1, loaders[1], cfg, autocast_bf16=True), task_id=1, online_factor=of)
+    _fisher_checks(f2, g, "fisher2", 2e-2)
+    sd2 = R.perturb(sd1, seed=int(g["seed"]) + 2, std=2e-3)
+    f3 = R.ewc_online_update(f2, R.ewc_importances(sd2, loaders[0], cfg, autocast_bf16=True), task_id=2, online_factor=of)
+    _fisher_checks(f3, g, "fisher3", 2e-2)
+    # fp32 importances differ from the autocast ones by far less than the terms themselves (sanity of the tolerance above)
+    f32 = R.ewc_importances(sd0, loaders[0], cfg, autocast_bf16=False)
+    tot = lambda d: sum(float(v.double().sum()) for v in d.values())
+    assert abs(tot(f32) - tot(f1)) <= 5e-2 * tot(f32)
+
+
+def test_ewc_penalty_step_exact_with_synthetic_fisher():
+    cfg, g, sd0, sd1, loaders, batch, syn = ewc_setup()
+    lam = float(g["reg_lambda"])
+    params = {k: v.clone().requires_grad_(True) for k, v in sd1.items()}
+    ce = R.forward(params, batch, cfg).loss
+    total = ce + R.ewc_penalty(params, sd0, syn, lam)
+    total.backward()
+    close(float(ce), float(g["step_syn/ce"]))
+    close(float(total), float(g["step_syn/total"]), 1e-5)
+    names, norms, gtot = grads_of(params, cfg)
+    close(norms, g["step_syn/grad_norms"], 1e-5)
+    close(gtot, float(g["step_syn/grad_total"]), 1e-5)
+    for key in g.files:
+        if key.startswith("step_syn/grad/") and not key.endswith(("/rows4", "/rowsum", "/colsum")):
+            close(params[key[len("step_syn/grad/"):]].grad.numpy(), g[key], 1e-5)
+
+
+def test_ewc_penalty_step_with_reference_fisher():
+    cfg, g, sd0, sd1, loaders, batch, syn = ewc_setup()
+    lam = float(g["reg_lambda"])
+    f1 = R.ewc_importances(sd0, loaders[0], cfg, autocast_bf16=True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd1.items()}
+    ce = R.forward(params, batch, cfg).loss
+    total = ce + R.ewc_penalty(params, sd0, f1, lam)
+    close(float(ce), float(g["step/ce"]))
+    close(float(total), float(g["step/total"]), 5e-2)
