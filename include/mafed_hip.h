@@ -126,6 +126,17 @@ int mafed_attn_bwd_colsum(const void* qkv, const void* out, const void* dout, co
                           int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                           const int64_t* attention_mask, int T, void* dqkv, float* delta, float* dqkv_colsum, void* stream);
 
+/* ---- KV-cached greedy decode (mafed/model/vqa_cont_learner.py:260-277 calls
+ * generate(max_new_tokens=10, use_cache=False), i.e. ten full forwards over the 256 + T prefix) ---------------------
+ * One new query per sample against every earlier key.  qkv_prefix [B,S0,H,3,D] is what the prefill's fused QKV GEMM wrote
+ * (k un-rotated; rotation applied on load, position = key index, as in mafed_attn_fwd); qkv_new [B,cap,H,3,D] holds one
+ * row per generated token, row t being the current one (its q is the query, position S0 + t; keys = S0 + t + 1).
+ * rot_cos / rot_sin cover at least S0 + t + 1 positions.  attention_mask [B,T] is the PROMPT's key-padding mask (P = S0 - T
+ * image keys and all generated keys are valid).  out [B,H*D] in dtype. */
+int mafed_attn_decode(const void* qkv_prefix, int S0, const void* qkv_new, int cap, int t, mafed_dtype dtype,
+                      int B, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                      const int64_t* attention_mask, int T, void* out, void* stream);
+
 /* ---- online EWC penalty (mafed/methods/ewc.py:105-127) -------------------------------------
  * The reference's compute_regularization over named_parameters(), on the flat fp32 buffers:
  *   fwd: out[0] = beta * out[0] + half_lambda * sum_i fisher[i] * (p[i] - p_old[i])^2     (half_lambda = 0.5 * reg_lambda;

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mafed_gemm": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p]),
     "mafed_gemm_colsum": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p, _p]),
     "mafed_gemm_set_variant": (_i, [_i]),
+    "mafed_attn_decode": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "mafed_ewc_workspace_bytes": (_z, [_l]),
     "mafed_ewc_penalty_fwd": (_i, [_p, _p, _p, _l, _f, _f, _p, _p, _z, _p]),
     "mafed_ewc_penalty_bwd": (_i, [_p, _p, _p, _l, _f, _p, _p, _p]),

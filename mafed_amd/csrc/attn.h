@@ -15,6 +15,10 @@ template <typename T>
 int attn_ref_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,
                         const float* rs, const int64_t* am, void* dqkv, float* delta, hipStream_t st);
 
+template <typename T>
+int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
+                       const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st);
+
 int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
                          hipStream_t st);
 int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, const AttnShape& sh, const float* rc,

@@ -225,6 +225,78 @@ int attn_ref_bwd_launch(const void* qkv, const void* out, const void* dout, cons
   return MAFED_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// KV-cached decode: ONE new query per sample against every earlier key.  The cache is the
+// [B,S0,H,3,D] qkv tensor the prefill's fused QKV GEMM left behind (k stays un-rotated; the rotation is applied on load,
+// position = key index, exactly like the training kernels) plus a small [B,cap,H,3,D] tensor that receives one row per
+// generated token.  One wave per (batch, head): scores lane-parallel over keys, output lane-parallel over the head dim.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv_pre, int S0, const T* __restrict__ qkv_new, int cap, int t,
+                                                          int B, int H, int D, int rot, int P, int Tm, const float* __restrict__ rc,
+                                                          const float* __restrict__ rs, const int64_t* __restrict__ am, T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int id = blockIdx.x * 4 + wave;
+  const int nk = S0 + t + 1, half = rot >> 1;
+  float* qrow = lds + (size_t)wave * (D + nk);
+  float* sc = qrow + D;
+  if (id >= B * H) return;
+  const int b = id / H, h = id - b * H;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const T* pre = qkv_pre + ((int64_t)b * S0 * H + h) * 3 * D;
+  const T* neu = qkv_new + ((int64_t)b * cap * H + h) * 3 * D;
+  const int qpos = S0 + t;
+  const T* qp = neu + (int64_t)t * rstride;
+  for (int d = lane; d < D; d += 64) qrow[d] = rot_elem(qp, d, rot, rc + (int64_t)qpos * half, rs + (int64_t)qpos * half);
+  __builtin_amdgcn_wave_barrier();
+  const float scale = rsqrtf((float)D);
+  float m = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
+    float s = -INFINITY;
+    if (j >= S0 || key_valid(am, b, j, P, Tm)) {
+      const T* kp = (j < S0 ? pre + (int64_t)j * rstride : neu + (int64_t)(j - S0) * rstride) + D;
+      float acc = 0.f;
+      for (int d = 0; d < D; ++d) acc = fmaf(qrow[d], rot_elem(kp, d, rot, rc + (int64_t)j * half, rs + (int64_t)j * half), acc);
+      s = acc * scale;
+    }
+    sc[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    const float p = expf(sc[j] - m);
+    sc[j] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  __builtin_amdgcn_wave_barrier();
+  const float inv = 1.0f / l;
+  T* op = out + (int64_t)b * H * D + (int64_t)h * D;
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < S0; ++j) acc = fmaf(sc[j], Elem<T>::load(pre + (int64_t)j * rstride + 2 * D + d), acc);
+    for (int j = S0; j < nk; ++j) acc = fmaf(sc[j], Elem<T>::load(neu + (int64_t)(j - S0) * rstride + 2 * D + d), acc);
+    Elem<T>::store(op + d, acc * inv);
+  }
+}
+
+template <typename T>
+int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
+                       const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st) {
+  const size_t lds = (size_t)4 * (D + S0 + t + 1) * sizeof(float);
+  if (lds > 160 * 1024) { set_error("attn_decode: %d keys too many for this kernel", S0 + t + 1); return MAFED_EINVAL; }
+  auto k = attn_decode_kernel<T>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k<<<dim3((B * H + 3) / 4), dim3(256), lds, st>>>((const T*)qkv_pre, S0, (const T*)qkv_new, cap, t, B, H, D, rot, P, Tm, rc, rs, am, (T*)out);
+  return MAFED_OK;
+}
+template int attn_decode_launch<float>(const void*, int, const void*, int, int, int, int, int, int, int, int, const float*, const float*,
+                                       const int64_t*, void*, hipStream_t);
+template int attn_decode_launch<bf16_t>(const void*, int, const void*, int, int, int, int, int, int, int, int, const float*, const float*,
+                                        const int64_t*, void*, hipStream_t);
+
 template int attn_ref_fwd_launch<float>(const void*, const AttnShape&, const float*, const float*, const int64_t*, void*, float*, hipStream_t);
 template int attn_ref_fwd_launch<bf16_t>(const void*, const AttnShape&, const float*, const float*, const int64_t*, void*, float*, hipStream_t);
 template int attn_ref_bwd_launch<float>(const void*, const void*, const void*, const float*, const AttnShape&, const float*, const float*,

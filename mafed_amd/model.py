@@ -406,8 +406,103 @@ class VLPythiaForCausalLM(nn.Module):
                                   attention_mask.to(dev, torch.int64).contiguous(), None, True, train=False, n_hidden=n_hidden)
         return tuple(st["hidden"])
 
+    # ---- greedy decode -----------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None,
+                 patch_embeddings: Optional[torch.Tensor] = None, max_new_tokens: int = 10, use_cache: bool = True,
+                 pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = 0, do_sample: bool = False,
+                 return_step_logits: bool = False, **kwargs):
+        """Greedy search with the call signature the reference validation uses (mafed/model/vqa_cont_learner.py:260-267,
+        mafed/utils/eval_utils.py:170-177: ``generate(input_ids=, attention_mask=, pixel_values=, max_new_tokens=10,
+        use_cache=False, pad_token_id=eos)``) and HF ``greedy_search`` semantics (transformers 4.37.1): next token = argmax of
+        the last position, finished rows keep emitting ``pad_token_id``, the attention mask grows by ones, generation stops
+        when every row has produced ``eos_token_id`` (GPT-NeoX / Pythia: 0) or after ``max_new_tokens``.  Positions are
+        ``arange`` over [image | text | generated].
+
+        ``use_cache=False`` is the reference's literal behaviour -- the whole 256 + T + t prefix is pushed through the stack
+        again for every token.  ``use_cache=True`` (default here) runs the prefix once, keeps each layer's fused-QKV output as
+        the K/V cache and then moves ONE row per sample through the stack per token (``mafed_attn_decode``); both produce the
+        same tokens.  Returns [B, T + n_generated] like HF; with ``return_step_logits`` also the fp32 last-position logits of
+        every step [n, B, V]."""
+        if do_sample or kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("only greedy search is on the validation path")
+        if input_ids is None or (pixel_values is None and patch_embeddings is None):
+            raise ValueError("generate needs input_ids and pixel_values / patch_embeddings")
+        dev = self.flat_params.device
+        feats = (patch_embeddings if patch_embeddings is not None else self.get_patch_embeddings(pixel_values)).to(dev).contiguous()
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        am = (attention_mask if attention_mask is not None else torch.ones_like(input_ids)).to(dev, torch.int64).contiguous()
+        if eos_token_id is not None and pad_token_id is None:
+            pad_token_id = eos_token_id  # HF's fallback for open-end generation
+        B, T = ids.shape
+        unfinished = torch.ones(B, dtype=torch.int64, device=dev)
+        new_tokens, step_logits = [], []
+
+        def pick(last_logits):
+            nonlocal unfinished
+            nxt = last_logits.float().argmax(dim=-1)
+            if eos_token_id is not None:
+                nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+                unfinished = unfinished * (nxt != eos_token_id).to(torch.int64)
+            new_tokens.append(nxt)
+            if return_step_logits:
+                step_logits.append(last_logits.float())
+            return nxt
+
+        if not use_cache:
+            cur_ids, cur_am = ids, am
+            for _ in range(max_new_tokens):
+                st = self._engine_forward(feats, cur_ids, cur_am, None, False, train=False)
+                nxt = pick(st["logits"][:, -1, :])
+                cur_ids = torch.cat([cur_ids, nxt[:, None]], dim=1)
+                cur_am = torch.cat([cur_am, torch.ones_like(nxt)[:, None]], dim=1)
+        else:
+            st = self._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
+            cache = _DecodeCache(self, [l["qkv"] for l in st["layers"]], B, st["S"], max_new_tokens, am)
+            nxt = pick(st["logits"][:, -1, :])
+            for t in range(max_new_tokens - 1):
+                nxt = pick(self._engine_decode_step(nxt, t, cache))
+        gen = torch.stack(new_tokens, dim=1)
+        if eos_token_id is not None:
+            # HF leaves the loop as soon as every row has finished: the output is as long as the slowest row needed
+            done = (gen == eos_token_id).to(torch.int64).cumsum(1).clamp_(max=1)       # 1 from the first eos on
+            first = (done.shape[1] - done.sum(1)) + done[:, -1]                        # tokens up to and including the first eos
+            n_keep = int(first.max().clamp_(max=gen.shape[1]))
+            gen = gen[:, :n_keep]
+            step_logits = step_logits[:n_keep]
+        out = torch.cat([ids, gen], dim=1)
+        if return_step_logits:
+            return out, torch.stack(step_logits, dim=0)
+        return out
+
+    def _engine_decode_step(self, tokens: torch.Tensor, t: int, cache: "_DecodeCache") -> torch.Tensor:
+        """One token per sample through the stack: ``tokens`` [B] sit at position S0 + t; returns the logits [B, V]."""
+        cfg, cd = self.config, self.compute_dtype
+        h, H, D, L = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers
+        B, S0, rot = cache.B, cache.S0, cfg.rotary_ndims
+        cos, sin = self.rotary_tables(S0 + cache.cap)
+        w = self._w
+        x = self._p("gpt_neox.embed_in.weight").index_select(0, tokens)  # fp32 residual stream row
+        for i in range(L):
+            pre = f"gpt_neox.layers.{i}."
+            ln1, ln2, _, _ = ops.layernorm_fwd(x, self._p(pre + "input_layernorm.weight"), self._p(pre + "input_layernorm.bias"),
+                                               self._p(pre + "post_attention_layernorm.weight"), self._p(pre + "post_attention_layernorm.bias"),
+                                               cfg.layer_norm_eps, cd, save_stats=False)
+            # the new token's q | k | v row goes straight into the cache (row t of the per-layer [B, cap, 3*H*D] tensor)
+            ops.gemm(ln1, w(pre + "attention.query_key_value.weight"), False, True, bias=self._p(pre + "attention.query_key_value.bias"),
+                     out=cache.new[i][:, t, :])
+            ao = ops.attn_decode(cache.prefix[i], S0, cache.new[i], t, B, H, D, rot, cos, sin, cache.attention_mask)
+            attn = ops.gemm(ao, w(pre + "attention.dense.weight"), False, True, bias=self._p(pre + "attention.dense.bias"), out_dtype=cd)
+            a = ops.gemm(ln2, w(pre + "mlp.dense_h_to_4h.weight"), False, True, bias=self._p(pre + "mlp.dense_h_to_4h.bias"), epilogue=EPI_GELU)
+            x = ops.gemm(a, w(pre + "mlp.dense_4h_to_h.weight"), False, True, bias=self._p(pre + "mlp.dense_4h_to_h.bias"),
+                         out_dtype=torch.float32, res1=attn, res2=x)
+        lnf, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                         None, None, cfg.layer_norm_eps, cd, save_stats=False)
+        return ops.gemm(lnf, w("embed_out.weight"), False, True)
+
     # ---- engine ------------------------------------------------------------------------------------------------------
-    def _engine_forward(self, feats, input_ids, attention_mask, labels, want_hidden, train, n_hidden: Optional[int] = None):
+    def _engine_forward(self, feats, input_ids, attention_mask, labels, want_hidden, train, n_hidden: Optional[int] = None,
+                        keep_qkv: bool = False):
         if not self.flat_params.is_cuda:
             raise RuntimeError("mafed_amd runs on the GPU only (no CPU fallback); move the model with .cuda()")
         if self._shadow_dirty:
@@ -451,6 +546,8 @@ class VLPythiaForCausalLM(nn.Module):
                           out_dtype=torch.float32, res1=attn, res2=x)
             if train:
                 sv["layers"].append({"x": x, "mean": mean, "rstd": rstd, "ln1": ln1, "ln2": ln2, "qkv": qkv, "ao": ao, "lse": lse, "u": u, "a": a})
+            elif keep_qkv:
+                sv["layers"].append({"qkv": qkv})  # the prefill's K/V cache: exactly what the fused QKV GEMM wrote
             x = xn
             if i < L - 1:
                 hidden.append(x.view(B, S, h))
@@ -633,6 +730,16 @@ class VLPythiaForCausalLM(nn.Module):
             for st in sides:
                 main.wait_stream(st)  # gradients complete (and `keep` safe to release) from the main stream's point of view
         keep.clear()
+
+
+class _DecodeCache:
+    """K/V cache of a greedy decode: per layer the prefill's [B*S0, 3*H*D] fused-QKV output (kept as written -- no split, no
+    transpose, k un-rotated) and a [B, cap, 3*H*D] tensor that receives one row per generated token."""
+
+    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor):
+        self.prefix, self.B, self.S0, self.cap, self.attention_mask = prefix, B, S0, max(1, cap), attention_mask
+        n = 3 * model.config.num_attention_heads * model.config.head_dim
+        self.new = [torch.zeros((B, self.cap, n), dtype=prefix[0].dtype, device=prefix[0].device) for _ in prefix]
 
 
 class _ModelFn(torch.autograd.Function):

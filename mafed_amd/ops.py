@@ -181,6 +181,19 @@ def attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, attention_mask, col
     return dqkv
 
 
+def attn_decode(qkv_prefix: torch.Tensor, S0: int, qkv_new: torch.Tensor, t: int, B: int, H: int, D: int, rot: int, cos, sin,
+                attention_mask: torch.Tensor) -> torch.Tensor:
+    """One decode step of attention: query = row t of ``qkv_new`` [B,cap,3*H*D], keys = the prefill's ``qkv_prefix``
+    [B*S0, 3*H*D] followed by rows 0..t of ``qkv_new``.  -> [B, H*D]"""
+    cap = qkv_new.shape[1]
+    assert qkv_new.dim() == 3 and qkv_new.is_contiguous() and qkv_prefix.is_contiguous() and qkv_new.dtype == qkv_prefix.dtype
+    assert cos.shape[0] >= S0 + t + 1
+    out = torch.empty((B, H * D), dtype=qkv_new.dtype, device=qkv_new.device)
+    check(_lib.load().mafed_attn_decode(_ptr(qkv_prefix), S0, _ptr(qkv_new), cap, t, _dt(qkv_new), B, H, D, rot, _ptr(cos), _ptr(sin),
+                                        _ptr(attention_mask), attention_mask.shape[1], _ptr(out), _stream()), "mafed_attn_decode")
+    return out
+
+
 def embed_concat_fwd(image: torch.Tensor, embed_in: torch.Tensor, input_ids: torch.Tensor, B: int, P: int, T: int) -> torch.Tensor:
     V, h = embed_in.shape
     h0 = torch.empty((B * (P + T), h), dtype=torch.float32, device=embed_in.device)

@@ -462,6 +462,52 @@ def gen_ewc_fixture(refs, name="t64", seed=21, reg_lambda=10000.0):
     print("ewc fixture ok: ce %.5f total %.5f (synthetic Fisher: %.5f)" % (float(ce), float(total), float(total2)))
 
 
+def gen_decode_fixture(refs, seed=31):
+    """SURVEY.md section 8f-3.  The reference's ``generate`` comes from HF's GenerationMixin, which the installed transformers
+    5.x no longer mixes into PreTrainedModel (the reference pins 4.37.1), so the fixture is built from what that call
+    computes step by step: the reference model's OWN forward on the growing sequence (use_cache=False re-runs the full
+    prefix per token) inside the published greedy-search loop (oracle generate_greedy with logits_fn = reference forward)."""
+    vp = refs[0]
+    out = {"seed": np.int64(seed)}
+    # (case, tiny config, eos): with random weights no fixed id ever wins the argmax, so the early-stop case takes as eos the
+    # token row 0 emits at its third step -- row 0 then finishes early and keeps emitting the pad id while the others go on
+    picked = {}
+    for case, name, eos in (("t64", "t64", None), ("t64_eos", "t64", "pick"), ("t64_row0", "t64", "pick"), ("m64", "m64", None),
+                            ("t128", "t128", None)):
+        cfg = tiny_cfg(name)
+        t = TINY[name]
+        sd = R.init_weights(cfg, seed=seed)
+        model = build_ref_model(vp, cfg, sd)
+        model.eval()
+        batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 1, pad=True)
+        if case.endswith("_row0"):  # a single row: generation ends as soon as that row emits eos (output shorter than max_new)
+            batch = {k: v[:1].clone() for k, v in batch.items()}
+        pv = ref_batch(batch, drop_labels=True)["pixel_values"]
+
+        def ref_logits(ids, am):
+            with torch.no_grad():
+                return model(input_ids=ids, attention_mask=am, pixel_values=pv, return_dict=True).logits
+
+        if eos == "pick":
+            eos = int(picked[name][0, t["T"] + 2])
+        n_new = 10 if name != "m64" else 6
+        ids, steps = R.generate_greedy(sd, batch, cfg, max_new_tokens=n_new, eos_token_id=eos, logits_fn=ref_logits)
+        picked.setdefault(name, ids)
+        # the oracle's own forward inside the same loop must agree (pins the restatement, not only the loop)
+        ids2, steps2 = R.generate_greedy(sd, batch, cfg, max_new_tokens=n_new, eos_token_id=eos)
+        assert torch.equal(ids, ids2), (case, ids, ids2)
+        assert float((steps - steps2).abs().max()) < 2e-5 * max(1.0, float(steps.abs().max()))
+        out[f"{case}/tokens"] = np_(ids)
+        out[f"{case}/step_logits"] = np_(steps)
+        out[f"{case}/eos"] = np.int64(-1 if eos is None else eos)
+        out[f"{case}/max_new"] = np.int64(n_new)
+        top2 = steps.topk(2, dim=-1).values
+        out[f"{case}/top2_gap"] = np_(top2[..., 0] - top2[..., 1])
+        print("decode fixture", case, "eos", eos, "generated", ids.shape[1] - t["T"], "tokens; min top-2 gap %.3e" % float((top2[..., 0] - top2[..., 1]).min()),
+              "| row 0:", ids[0, t["T"]:].tolist())
+    np.savez_compressed(os.path.join(OUT, "decode.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import logging
@@ -476,6 +522,7 @@ def main():
     gen_trainer_fixture(refs)
     gen_optim_fixture(refs)
     gen_ewc_fixture(refs)
+    gen_decode_fixture(refs)
 
 
 if __name__ == "__main__":

@@ -449,6 +449,43 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Greedy validation decode (mafed/model/vqa_cont_learner.py:260-267, utils/eval_utils.py:170-177)
+# ---------------------------------------------------------------------------------------------------------------
+def generate_greedy(sd, batch, cfg: RefConfig, max_new_tokens: int = 10, eos_token_id: Optional[int] = 0,
+                    pad_token_id: Optional[int] = None, logits_fn=None):
+    """``generate(max_new_tokens=10, use_cache=False, pad_token_id=eos)`` as HF 4.37.1 ``greedy_search`` runs it: every step
+    pushes the whole [image | prompt | generated] sequence through the model again, takes the argmax of the last position,
+    overwrites the tokens of finished rows with ``pad_token_id``, appends a 1 to the attention mask, and stops once every row
+    has emitted ``eos_token_id``.  ``logits_fn(input_ids, attention_mask) -> [B, T', V]`` lets the golden generator run the
+    same loop around the reference model's own forward.  Returns (tokens [B, T + n], last-position logits [n, B, V])."""
+    if eos_token_id is not None and pad_token_id is None:
+        pad_token_id = eos_token_id
+    if logits_fn is None:
+        def logits_fn(ids, am):
+            b = {"input_ids": ids, "attention_mask": am, "patch_embeddings": batch["patch_embeddings"]}
+            with torch.no_grad():
+                return forward(sd, b, cfg).logits
+    ids, am = batch["input_ids"].clone(), batch["attention_mask"].clone()
+    T0 = ids.shape[1]
+    unfinished = torch.ones(ids.shape[0], dtype=torch.int64)
+    steps = []
+    for _ in range(max_new_tokens):
+        last = logits_fn(ids, am)[:, -1, :].float()
+        steps.append(last)
+        nxt = last.argmax(dim=-1)
+        if eos_token_id is not None:
+            nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+        ids = torch.cat([ids, nxt[:, None]], dim=1)
+        am = torch.cat([am, torch.ones_like(nxt)[:, None]], dim=1)
+        if eos_token_id is not None:
+            unfinished = unfinished * (nxt != eos_token_id).to(torch.int64)
+            if int(unfinished.max()) == 0:
+                break
+    assert ids.shape[1] == T0 + len(steps)
+    return ids, torch.stack(steps, dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Online EWC (SURVEY.md section 8f-4; mafed/methods/ewc.py)
 # ---------------------------------------------------------------------------------------------------------------
 def ewc_importances(sd: Dict[str, torch.Tensor], batches: Sequence[Dict[str, torch.Tensor]], cfg: RefConfig,

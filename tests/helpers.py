@@ -76,3 +76,21 @@ def ewc_setup(name="t64"):
     batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 5, pad=True)
     syn = {k: v.abs() for k, v in R.init_weights(cfg, seed=seed + 7).items()}
     return cfg, g, sd0, sd1, loaders, batch, syn
+
+
+DECODE_CASES = {"t64": "t64", "t64_eos": "t64", "t64_row0": "t64", "m64": "m64", "t128": "t128"}
+
+
+def decode_setup(case):
+    """Inputs of oracle/gen_golden.py::gen_decode_fixture: (cfg, weights, batch, eos or None, max_new, golden tokens, step logits, top-2 gaps)."""
+    g = load_golden("decode.npz")
+    name = DECODE_CASES[case]
+    cfg, t = tiny_cfg(name), TINY[name]
+    seed = int(g["seed"])
+    sd = R.init_weights(cfg, seed=seed)
+    batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 1, pad=True)
+    if case.endswith("_row0"):
+        batch = {k: v[:1].clone() for k, v in batch.items()}
+    eos = int(g[f"{case}/eos"])
+    return (cfg, sd, batch, None if eos < 0 else eos, int(g[f"{case}/max_new"]), torch.from_numpy(g[f"{case}/tokens"]),
+            torch.from_numpy(g[f"{case}/step_logits"]), torch.from_numpy(g[f"{case}/top2_gap"]))

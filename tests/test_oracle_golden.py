@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vlpythia_ref as R
-from tests.helpers import G3_VARIANTS, TINY, ewc_setup, g3_spec, golden_setup, load_golden
+from tests.helpers import DECODE_CASES, G3_VARIANTS, TINY, decode_setup, ewc_setup, g3_spec, golden_setup, load_golden
 
 TOL = 2e-5
 
@@ -193,3 +193,20 @@ def test_ewc_penalty_step_with_reference_fisher():
     total = ce + R.ewc_penalty(params, sd0, f1, lam)
     close(float(ce), float(g["step/ce"]))
     close(float(total), float(g["step/total"]), 5e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# greedy validation decode against the reference model's own forward in the greedy loop
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", list(DECODE_CASES))
+def test_greedy_decode(case):
+    cfg, sd, batch, eos, max_new, tokens, step_logits, gaps = decode_setup(case)
+    ids, steps = R.generate_greedy(sd, batch, cfg, max_new_tokens=max_new, eos_token_id=eos)
+    assert torch.equal(ids, tokens)
+    close(steps.numpy(), step_logits.numpy())
+    T = batch["input_ids"].shape[1]
+    if case == "t64_row0":
+        assert ids.shape[1] - T < max_new and int(ids[0, -1]) == eos  # stopped as soon as the only row emitted eos
+    if case == "t64_eos":
+        first = (ids[0, T:] == eos).nonzero()[0, 0]
+        assert bool((ids[0, T + int(first):] == eos).all())          # a finished row keeps emitting pad (= eos)
