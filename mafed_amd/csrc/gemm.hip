@@ -984,6 +984,13 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
                   (long long)M, (long long)K, transB, (long long)N);
   const bool a_ks = transA != 0, b_ks = transB == 0;
   int rc;
+  if (g_gemm_variant == 0 && gemm_skinny_ok(transA, transB, M, N, K, beta, colsum)) {
+    // one token per sample (decode): stream W once with N/16 blocks instead of N/128
+    rc = gemm_skinny_launch(M, N, K, A, lda, B, ldb, C, c_dtype, epi, st);
+    if (rc != MAFED_OK) return rc;
+    MAFED_CHECK_LAUNCH("gemm(bf16, skinny)");
+    return MAFED_OK;
+  }
   // variant: 0 automatic, 1 register-staged kernel, 10 + c forces LDS-DMA tile configuration c
   int cfg = -1;
   if (g_gemm_variant != 1 && K % 64 == 0) {

@@ -138,4 +138,9 @@ __device__ __forceinline__ void colsum_flush(float (&cs)[8], float* __restrict__
   }
 }
 
+// decode-path product (gemm_skinny.hip)
+bool gemm_skinny_ok(int transA, int transB, int64_t M, int64_t N, int64_t K, float beta, const void* colsum);
+int gemm_skinny_launch(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, mafed_dtype c_dtype,
+                       const GemmEpi& epi, hipStream_t st);
+
 }  // namespace mafed

@@ -113,6 +113,35 @@ def test_gemm_epilogues(dt):
     assert_close(y.float(), (Af @ Wf.t()) * uf.grad, tol, "gelu_bwd")
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 1024, 1024), (3, 48, 256), (64, 4096, 1024), (17, 50304, 512), (32, 1024, 4096), (1, 16, 256)])
+def test_gemm_skinny_decode_shapes(M, N, K):
+    """One token per sample (decode): the NT product with M <= 64 rows goes through the weight-streaming kernel (16-column
+    strips, K split over eight waves); all of its epilogues and a strided output (the K/V-cache row) against fp64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    X = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g)
+    ref = X.float().cpu().double() @ W.float().cpu().double().t()
+    scale = float(ref.abs().max())
+    y = ops.gemm(X, W, False, True)
+    assert_close(y.float(), ref, 1e-2, "plain")
+    assert torch.equal(y, ops.gemm(X, W, False, True)), "deterministic (LDS fold in a fixed order, no atomics)"
+    y = ops.gemm(X, W, False, True, bias=bias.to(DEV), epilogue=ops.EPI_GELU)
+    assert_close(y.float(), F.gelu(ref + bias.double()), 1e-2, "bias + gelu")
+    r1 = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    r2 = torch.randn(M, N, generator=g)
+    y = ops.gemm(X, W, False, True, bias=bias.to(DEV), out_dtype=torch.float32, res1=r1.to(DEV), res2=r2.to(DEV))
+    assert y.dtype == torch.float32
+    err = (y.cpu().double() - (ref + bias.double() + r1.double() + r2.double())).abs().max().item()
+    assert err <= 2e-3 * max(1.0, scale), err  # fp32 out: only the bf16 operands round
+    # strided destination: row t of a [M, cap, N] cache tensor
+    cache = torch.zeros(M, 3, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(X, W, False, True, bias=bias.to(DEV), out=cache[:, 1, :])
+    assert_close(cache[:, 1, :].float(), ref + bias.double(), 1e-2, "strided out")
+    assert float(cache[:, 0, :].abs().max()) == 0.0 and float(cache[:, 2, :].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("split", [100, 101, 102, 104, 108])
 def test_gemm_split_k_accumulate(split):
     """dW += dY^T.X with K split over blockIdx.y and fp32 atomics into the running gradient (100 = automatic choice)."""

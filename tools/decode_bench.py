@@ -1,0 +1,55 @@
+"""Validation decode at the headline shape (VLPythia-410M, B = 32, 256 image + 32 text tokens, 10 new tokens, bf16):
+the reference's use_cache=False recompute against the KV-cached path (run on the GPU box)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mafed_amd import VLPythiaConfig, VLPythiaForCausalLM
+
+B, P, T, NEW = 32, 256, 32, 10
+model_name = sys.argv[1] if len(sys.argv) > 1 else "410m"
+cfg = VLPythiaConfig.preset(model_name, num_vision_tokens=P)
+model = VLPythiaForCausalLM(cfg, compute_dtype=torch.bfloat16, device="cuda", seed=1234)
+g = torch.Generator().manual_seed(0)
+ids = torch.randint(1, cfg.vocab_size, (B, T), generator=g).cuda()
+am = torch.ones(B, T, dtype=torch.int64).cuda()
+feats = torch.randn(B, P, cfg.vision_hidden_size, generator=g).to(torch.bfloat16).cuda()
+
+
+def run(use_cache, reps=5):
+    kw = dict(input_ids=ids, attention_mask=am, patch_embeddings=feats, max_new_tokens=NEW, use_cache=use_cache, eos_token_id=None)
+    out = model.generate(**kw)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = model.generate(**kw)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best, out
+
+
+t_u, o_u = run(False)
+t_c, o_c = run(True)
+same = float((o_u == o_c).float().mean())
+n_params = sum(p.numel() for p in model.parameters())
+wbytes = 2.0 * (n_params - cfg.vocab_size * cfg.hidden_size)  # bf16 weights streamed per decode step (all but embed_in)
+print(f"{model_name}: generate B={B} {P}+{T} tokens, {NEW} new: recompute {t_u * 1e3:.1f} ms ({B / t_u:.0f} ex/s), "
+      f"KV-cached {t_c * 1e3:.1f} ms ({B / t_c:.0f} ex/s), speed-up {t_u / t_c:.2f}x, tokens equal {same:.3f}")
+# decode-step roofline: the (NEW - 1) cached steps stream the weights once each
+st = model._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
+from mafed_amd.model import _DecodeCache
+cache = _DecodeCache(model, [l["qkv"] for l in st["layers"]], B, st["S"], NEW, am)
+tok = ids[:, -1].contiguous()
+for t in range(3):
+    model._engine_decode_step(tok, t, cache)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for t in range(NEW - 1):
+    model._engine_decode_step(tok, t, cache)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / (NEW - 1)
+print(f"decode step: {ms:.3f} ms; weights {wbytes / 1e9:.2f} GB per step -> {wbytes / ms / 1e9:.2f} TB/s ({wbytes / ms / 1e9 / 8.0 * 100:.1f} % of 8 TB/s)")
