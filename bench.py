@@ -179,14 +179,16 @@ def main():
 
     # live roofline of the dominant kernel: two more steps, launched eagerly so that every bf16 MFMA GEMM launch can be
     # bracketed by HIP events on its own stream (same kernels, same streams/overlap as the replayed graph; not part of `value`)
-    if rank == 0 and not args.no_gemm_events:
+    # (every rank takes these steps -- they contain the gradient all-reduce -- but only rank 0 records events)
+    ev_alone = None
+    if not args.no_gemm_events:
         graphs_on = tr.use_graphs
         tr.use_graphs = False
-        ops.GEMM_EVENTS = []
+        ops.GEMM_EVENTS = [] if rank == 0 else None
         for i in range(2):
             tr.step(task_batch, args.warmup + args.steps + i)
         torch.cuda.synchronize()
-        ev_overlapped, ops.GEMM_EVENTS = ops.GEMM_EVENTS, []
+        ev_overlapped, ops.GEMM_EVENTS = ops.GEMM_EVENTS, ([] if rank == 0 else None)
         # ... and two steps with the side streams switched off (dW GEMMs and the teacher forward in line on the main
         # stream): every GEMM then has the chip to itself, which is the number a per-kernel roofline should be read against
         ov = (student.overlap_param_grads, fd.overlap_teacher)
@@ -197,8 +199,7 @@ def main():
         student.overlap_param_grads, fd.overlap_teacher = ov
         ev_alone, ops.GEMM_EVENTS = ops.GEMM_EVENTS, ev_overlapped
         tr.use_graphs = graphs_on
-    else:
-        ev_alone = None
+        barrier()
     if rank == 0:
         samples = args.steps * B * world
         value = samples / dt

@@ -115,7 +115,11 @@ def init_from_env(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # MAFED_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks on ONE GPU (RCCL needs a device per rank)
+        backend = backend or os.environ.get("MAFED_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            if backend != "nccl":
+                local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
