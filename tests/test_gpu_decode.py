@@ -76,6 +76,25 @@ def test_generate_bf16_cached_equals_uncached_and_tracks_fp32(case):
         assert torch.equal(out_c[:, T + i], out_u[:, T + i]) and torch.equal(out_c[:, T + i].cpu(), tokens[:, T + i])
 
 
+@pytest.mark.parametrize("case", ["t64", "t64_eos", "t128"])
+def test_generate_graph_replay_equals_eager(case):
+    """use_graph=True: the decode steps replayed from one hipGraph (static K/V cache written by the prefill) give the golden
+    tokens, twice in a row (second call = pure replay with new inputs)."""
+    cfg, sd, batch, eos, max_new, tokens, step_logits, gaps = decode_setup(case)
+    model = build_model(cfg, sd)
+    b = to_dev(batch)
+    kw = dict(attention_mask=b["attention_mask"], patch_embeddings=b["patch_embeddings"], max_new_tokens=max_new, eos_token_id=eos,
+              pad_token_id=eos, use_cache=True, use_graph=True)
+    out1 = model.generate(input_ids=b["input_ids"], **kw)
+    assert torch.equal(out1.cpu(), tokens)
+    # same shapes, different prompt: rows rolled by one -> outputs roll with them
+    rolled = {k: torch.roll(v, 1, dims=0) for k, v in b.items()}
+    out2 = model.generate(input_ids=rolled["input_ids"], **{**kw, "attention_mask": rolled["attention_mask"], "patch_embeddings": rolled["patch_embeddings"]})
+    if eos is None:
+        assert torch.equal(out2.cpu(), torch.roll(tokens, 1, dims=0))
+    assert len(model._decode_graphs) == 1
+
+
 def test_generate_call_signature_of_the_reference_validation_step():
     """mafed/model/vqa_cont_learner.py:260-267: pixel_values features + use_cache=False + pad_token_id=eos."""
     cfg, sd, batch, eos, max_new, tokens, step_logits, gaps = decode_setup("t64")

@@ -17,8 +17,9 @@ am = torch.ones(B, T, dtype=torch.int64).cuda()
 feats = torch.randn(B, P, cfg.vision_hidden_size, generator=g).to(torch.bfloat16).cuda()
 
 
-def run(use_cache, reps=5):
-    kw = dict(input_ids=ids, attention_mask=am, patch_embeddings=feats, max_new_tokens=NEW, use_cache=use_cache, eos_token_id=None)
+def run(use_cache, reps=5, use_graph=False):
+    kw = dict(input_ids=ids, attention_mask=am, patch_embeddings=feats, max_new_tokens=NEW, use_cache=use_cache, eos_token_id=None,
+              use_graph=use_graph)
     out = model.generate(**kw)
     torch.cuda.synchronize()
     best = 1e9
@@ -31,12 +32,15 @@ def run(use_cache, reps=5):
 
 
 t_u, o_u = run(False)
-t_c, o_c = run(True)
+t_e, o_e = run(True)
+t_c, o_c = run(True, use_graph=True)
 same = float((o_u == o_c).float().mean())
+assert torch.equal(o_e, o_c), "graph replay and eager launches must produce the same tokens"
 n_params = sum(p.numel() for p in model.parameters())
 wbytes = 2.0 * (n_params - cfg.vocab_size * cfg.hidden_size)  # bf16 weights streamed per decode step (all but embed_in)
 print(f"{model_name}: generate B={B} {P}+{T} tokens, {NEW} new: recompute {t_u * 1e3:.1f} ms ({B / t_u:.0f} ex/s), "
-      f"KV-cached {t_c * 1e3:.1f} ms ({B / t_c:.0f} ex/s), speed-up {t_u / t_c:.2f}x, tokens equal {same:.3f}")
+      f"KV-cached eager {t_e * 1e3:.1f} ms, KV-cached + hipGraph {t_c * 1e3:.1f} ms ({B / t_c:.0f} ex/s), speed-up {t_u / t_c:.2f}x, "
+      f"tokens equal {same:.3f}")
 # decode-step roofline: the (NEW - 1) cached steps stream the weights once each
 st = model._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
 from mafed_amd.model import _DecodeCache
