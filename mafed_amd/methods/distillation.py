@@ -20,6 +20,10 @@ from mafed_amd.methods.distillation_loss_weights import DistillationWeights
 from mafed_amd.methods.memory import HBMReplayBuffer
 
 
+import os as _os
+_EARLY_SUMS = _os.environ.get("MAFED_EARLY_SUMS", "1") == "1"
+
+
 class _DistillSumsFn(torch.autograd.Function):
     """sums[l] = {sum_lang d, sum_vision d, n_lang, n_vision} for every distilled layer l (d = per-token MSE or 1-cos)."""
 
@@ -53,11 +57,16 @@ class _FusedDistillSumsFn(torch.autograd.Function):
     (mafed_layernorm_bwd, teacher != NULL) -- no per-layer gradient tensor, no separate add / cast pass."""
 
     @staticmethod
-    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, *student):
+    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, early, *student):
         nl = len(student)
-        out = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
-        for l in range(nl):
-            ops.distill_fwd(student[l], teacher[l], attention_mask, P, False, out=out[l])
+        if early is not None:
+            # the sums were started layer by layer during the student forward (FeatureDistillation._early_sums_hook)
+            out, ev = early
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            out = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
+            for l in range(nl):
+                ops.distill_fwd(student[l], teacher[l], attention_mask, P, False, out=out[l])
         ctx.sv, ctx.layers, ctx.teacher = sv, list(layers), list(teacher)
         return out
 
@@ -66,7 +75,7 @@ class _FusedDistillSumsFn(torch.autograd.Function):
         g = g.contiguous()
         ctx.sv["inject"] = {layer: (ctx.teacher[k], g[k]) for k, layer in enumerate(ctx.layers)}
         ctx.sv = None
-        return (torch.zeros((), device=g.device), None, None, None, None, None) + (None,) * len(ctx.layers)
+        return (torch.zeros((), device=g.device), None, None, None, None, None, None) + (None,) * len(ctx.layers)
 
 
 class _DistillClsFn(torch.autograd.Function):
@@ -185,13 +194,53 @@ class FeatureDistillation(CLStrategy):
         if self.distillation_coeff != 0:
             # frozen-teacher forward on a second HIP stream, concurrent with the student's
             self._prefetch_teacher(batch, getattr(self.mem_dataloader, "last_ready_event", None))
-        output = model(**batch, compute_loss=do_replay, output_hidden_states=True, return_dict=True)
+        hooked = self._install_early_sums(model, batch)
+        try:
+            output = model(**batch, compute_loss=do_replay, output_hidden_states=True, return_dict=True)
+        finally:
+            if hooked:
+                model.hidden_ready_hook = None
         loss = self.replay_coeff * output.loss if do_replay else None
         if self.distillation_coeff == 0:
             return loss, n_ex
         dloss = self.distill(output=output, batch=batch)
         loss = dloss if loss is None else loss + dloss
         return loss, n_ex
+
+    def _install_early_sums(self, model, batch) -> bool:
+        """Fused MSE path only: start each distilled layer's masked sums (one HBM-bound pass over student + teacher states)
+        as soon as the student forward has produced that hidden state, on the teacher's stream, instead of running all of
+        them back to back after the forward -- they then run under the following layers' GEMMs."""
+        self._early = None
+        pre = getattr(self, "_prefetched", None)
+        if (not _EARLY_SUMS or pre is None or self._cosine or self._cls_distillation or not self.fused_distill or not self.overlap_teacher
+                or not hasattr(model, "hidden_ready_hook") or not torch.is_grad_enabled()):
+            return False
+        hs, ev, n = pre
+        layers = list(self.loss_weights.get_distillation_layers())
+        if not layers or max(layers) + 1 > n:
+            return False
+        dev = hs[0].device
+        am = batch["attention_mask"].to(dev, torch.int64).contiguous()
+        P = self.num_vision_tokens
+        B, T = am.shape
+        side = self.past_model.side_stream()
+        sums = torch.empty((len(layers), 4), dtype=torch.float32, device=dev)
+        slot = {l: k for k, l in enumerate(layers)}
+        state = {"sums": sums, "stream": side, "layers": layers, "n": len(layers)}
+
+        def hook(l, x):
+            k = slot.get(l)
+            if k is None:
+                return
+            main = torch.cuda.current_stream()
+            side.wait_event(main.record_event())   # hidden_states[l] is final on the caller's stream
+            with torch.cuda.stream(side):           # (the teacher forward that produced hs[l] ran on this very stream)
+                ops.distill_fwd(x.view(B, P + T, -1), hs[l], am, P, False, out=sums[k])
+
+        model.hidden_ready_hook = hook
+        self._early = state
+        return True
 
     def _prefetch_teacher(self, batch, batch_ready_event=None):
         """Issue the teacher forward on its own stream before the student's (same arithmetic, earlier in time): the two
@@ -264,7 +313,13 @@ class FeatureDistillation(CLStrategy):
             teachers = [past[l] for l in layers]
             mctx = getattr(output, "mafed_ctx", None)
             if self.fused_distill and not self._cosine and mctx is not None:
-                sums = _FusedDistillSumsFn.apply(mctx[1], am, P, teachers, mctx[0], layers, *students)  # [nl, 4]
+                early = getattr(self, "_early", None)
+                self._early = None
+                if early is not None and (early["layers"] != list(layers) or early["n"] != len(layers)):
+                    early = None
+                sums = _FusedDistillSumsFn.apply(mctx[1], am, P, teachers, mctx[0], layers,
+                                                 (early["sums"], early["stream"].record_event()) if early is not None else None,
+                                                 *students)  # [nl, 4]
             else:
                 sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
             lang = sums[:, 0] / sums[:, 2]

@@ -175,6 +175,9 @@ class VLPythiaForCausalLM(nn.Module):
         # callable(i): fired when layer i's parameter gradients are final for this backward; i = L for the LM head /
         # final LayerNorm, -1 when everything (embeddings, projector) is done.  Used by the DDP bucket reducer.
         self.grad_ready_hook = None
+        # callable(l, x): fired in a training forward as soon as hidden_states[l] (fp32 [rows, h]) is final; the MAFED plugin
+        # uses it to start that layer's distillation sums on a side stream, under the following layers' GEMMs
+        self.hidden_ready_hook = None
         self._side = None
         self._view_cache: Dict[Tuple[int, str], torch.Tensor] = {}
         self.overlap_param_grads = True  # run dW / bias-gradient kernels on side_stream() concurrently with the dX chain
@@ -542,6 +545,9 @@ class VLPythiaForCausalLM(nn.Module):
         if train:
             sv["proj"] = (fc, u0, a0)
         hidden = [x.view(B, S, h)]
+        hook = self.hidden_ready_hook if train else None
+        if hook is not None:
+            hook(0, x)
         n_layers = L if n_hidden is None else max(0, min(L, n_hidden - 1))
         for i in range(n_layers):
             pre = f"gpt_neox.layers.{i}."
@@ -565,6 +571,8 @@ class VLPythiaForCausalLM(nn.Module):
             x = xn
             if i < L - 1:
                 hidden.append(x.view(B, S, h))
+                if hook is not None:
+                    hook(i + 1, x)
         sv["hidden"] = hidden
         sv["loss"] = None
         sv["logits"] = None
