@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="replay the step from a hipGraph (measured slower than eager launches on ROCm 7: 42.9 vs 39.7 ms)")
     ap.add_argument("--no-graphs", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
+    ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
     args = ap.parse_args()
 
@@ -141,7 +142,8 @@ def main():
     fd.mem_dataloader = mem
     conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=1, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_perc=0.1)
-    tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, use_graphs=args.graphs and not args.no_graphs)
+    tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, use_graphs=args.graphs and not args.no_graphs,
+                 pipeline_optimizer=not args.no_pipeline_optimizer)
     task_batch = mem.sample()  # dropped by a replay step, as in the reference
 
     def barrier():

@@ -178,6 +178,8 @@ class VLPythiaForCausalLM(nn.Module):
         # callable(l, x): fired in a training forward as soon as hidden_states[l] (fp32 [rows, h]) is final; the MAFED plugin
         # uses it to start that layer's distillation sums on a side stream, under the following layers' GEMMs
         self.hidden_ready_hook = None
+        # {"pre" | ("layer", i) | "head": event} left by FlatAdamW.apply_pipelined: the forward waits chunk by chunk
+        self._param_events = None
         self._side = None
         self._view_cache: Dict[Tuple[int, str], torch.Tensor] = {}
         self.overlap_param_grads = True  # run dW / bias-gradient kernels on side_stream() concurrently with the dX chain
@@ -521,6 +523,9 @@ class VLPythiaForCausalLM(nn.Module):
                         keep_qkv: bool = False, qkv_out: Optional[Sequence[torch.Tensor]] = None):
         if not self.flat_params.is_cuda:
             raise RuntimeError("mafed_amd runs on the GPU only (no CPU fallback); move the model with .cuda()")
+        pe, main_st = self._param_events, torch.cuda.current_stream()
+        if pe is not None:
+            main_st.wait_event(pe["pre"])
         if self._shadow_dirty:
             self.sync_shadow()
         cfg, cd = self.config, self.compute_dtype
@@ -551,6 +556,8 @@ class VLPythiaForCausalLM(nn.Module):
         n_layers = L if n_hidden is None else max(0, min(L, n_hidden - 1))
         for i in range(n_layers):
             pre = f"gpt_neox.layers.{i}."
+            if pe is not None:
+                main_st.wait_event(pe[("layer", i)])
             ln1, ln2, mean, rstd = ops.layernorm_fwd(x, self._p(pre + "input_layernorm.weight"), self._p(pre + "input_layernorm.bias"),
                                                      self._p(pre + "post_attention_layernorm.weight"), self._p(pre + "post_attention_layernorm.bias"),
                                                      cfg.layer_norm_eps, cd, save_stats=train)
@@ -576,6 +583,11 @@ class VLPythiaForCausalLM(nn.Module):
         sv["hidden"] = hidden
         sv["loss"] = None
         sv["logits"] = None
+        if pe is not None:  # from here on the caller's stream is ordered behind every chunk of the pipelined update
+            for k in range(n_layers, L):
+                main_st.wait_event(pe[("layer", k)])
+            main_st.wait_event(pe["head"])
+            self._param_events = None
         if n_hidden is not None:
             return sv
         # final LN (fp32 hidden state L only when asked for) + LM head on the T text positions (vl_pythia.py:89,310)

@@ -109,6 +109,43 @@ class FlatAdamW:
         if m.flat_shadow is not None:
             m._shadow_dirty = False
 
+    def _chunks(self):
+        """(key, lo, hi, weight_decay) in the order the NEXT forward touches the parameters: everything the first kernels
+        read (all biases / non-decayed tensors, token embedding, projector), then the layers bottom-up, then final LN + head."""
+        from mafed_amd.dist import layer_ranges
+        m = self.model
+        wd = self.param_groups[0]["weight_decay"]
+        per_layer, head, tail = layer_ranges(m)
+        out = [("pre", tail[-1][0], tail[-1][1], 0.0)]               # the non-decayed segment
+        out += [("pre", lo, hi, wd) for lo, hi in tail[:-1]]          # embed_in, projector
+        out += [(("layer", i), lo, hi, wd) for i, (lo, hi) in enumerate(per_layer)]
+        out.append(("head", head[0], head[1], wd))
+        assert sum(hi - lo for _, lo, hi, _ in out) == m.flat_params.numel(), "optimizer chunks must tile the flat buffer"
+        return [c for c in out if c[2] > c[1]]
+
+    def apply_pipelined(self, stream, grad_mul: float = 1.0, zero_grads: bool = True):
+        """AdamW (and the gradient zeroing) chunk by chunk on ``stream``, one event per chunk group: the next forward waits
+        for "pre", then for ("layer", i) right before layer i, then for "head" -- so the HBM-bound update of the upper layers
+        runs under the MFMA-bound forward of the lower ones instead of in front of it.  The caller's stream must not touch
+        parameters, optimiser state or gradients until it has waited for these events (the model's forward does)."""
+        m = self.model
+        clip = self.clip_out if getattr(self, "_clip_pending", False) else None
+        main = torch.cuda.current_stream()
+        stream.wait_event(main.record_event())  # gradients final, clip scale and {lr, bias corrections} on the device
+        events = {}
+        with torch.cuda.stream(stream):
+            for key, lo, hi, wd in self._chunks():
+                shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
+                ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
+                                self.betas[0], self.betas[1], self.eps, wd, 0, clip, grad_mul, shadow)
+                if zero_grads:
+                    m.flat_grads[lo:hi].zero_()
+                events[key] = stream.record_event()
+        self._clip_pending = False
+        if m.flat_shadow is not None:
+            m._shadow_dirty = False
+        return events
+
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "sched": self._sched}
 

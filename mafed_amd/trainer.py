@@ -62,7 +62,8 @@ class _GraphedStep:
 
 class Trainer:
     def __init__(self, model, cl_method, config: Optional[Any] = None, task_id: int = 0, n_batches_per_epoch: int = 1000,
-                 process_group=None, ddp: bool = False, bucket_mb: float = 64.0, use_graphs: bool = False):
+                 process_group=None, ddp: bool = False, bucket_mb: float = 64.0, use_graphs: bool = False,
+                 pipeline_optimizer: bool = False):
         cfg = config if config is not None else SimpleNamespace()
         self.config = cfg
         self.model = model
@@ -84,6 +85,11 @@ class Trainer:
         # hipGraph replay of the device part of a step.  Needs fixed batch shapes and CL hooks that do no per-step host work
         # (true for Naive / ER / FeatureDistillation, whose update_after_* are no-ops on this path).
         self.use_graphs = bool(use_graphs) and self.reducer is None
+        # AdamW + gradient zeroing chunk by chunk on their own stream, the next forward waiting per layer (FlatAdamW.
+        # apply_pipelined).  Opt-in: between step() calls the caller's stream may then only reach the parameters through the
+        # model's forward, or after join().
+        self.pipeline_optimizer = bool(pipeline_optimizer) and not self.use_graphs and torch.cuda.is_available()
+        self._opt_stream = torch.cuda.Stream(device=model.flat_params.device) if self.pipeline_optimizer else None
         self._graphs: Dict[Any, _GraphedStep] = {}
         self._eager_seen: Dict[Any, int] = {}
         self.global_step = 0
@@ -131,10 +137,20 @@ class Trainer:
             if self.grad_norm and self.grad_norm > 0:
                 rec["grad_norm"] = self.optimizer.clip_grad_norm_(self.grad_norm).clone()
             self.optimizer.advance()
-            self.optimizer.apply()
-            self.optimizer.zero_grad()
+            if self.pipeline_optimizer:
+                self.model._param_events = self.optimizer.apply_pipelined(self._opt_stream)
+            else:
+                self.optimizer.apply()
+                self.optimizer.zero_grad()
             rec["stepped"] = True
         return rec
+
+    def join(self) -> None:
+        """Order the current stream behind a pipelined optimiser update (needed before parameters, gradients or optimiser
+        state are read by anything but the model's forward)."""
+        if self._opt_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self.model._param_events = None
 
     def step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, Any]:
         window_end = (batch_idx + 1) % self.accumulate == 0

@@ -160,8 +160,11 @@ def test_layer_strategy_errors_match_reference():
                             distillation_layer=11, num_hidden_layers=11)  # out of range -> None -> assertion
 
 
-def test_trainer_sequence_vs_reference_golden():
-    """8 micro-batches, task 1, replay_interval 4, accumulate 4: (branch, loss, grad-norm, lr, parameter checksum)."""
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_trainer_sequence_vs_reference_golden(pipeline):
+    """8 micro-batches, task 1, replay_interval 4, accumulate 4: (branch, loss, grad-norm, lr, parameter checksum).
+    pipeline=True: AdamW + gradient zeroing chunk by chunk on their own stream, the next forward waiting layer by layer
+    (Trainer(pipeline_optimizer=True), what bench.py runs); parameters are read after Trainer.join()."""
     from mafed_amd import FeatureDistillation, Trainer
     g = load_golden("trainer_t64.npz")
     name, seed = "t64", int(g["meta/seed"])
@@ -180,7 +183,8 @@ def test_trainer_sequence_vs_reference_golden():
     conf = types.SimpleNamespace(accumulate_grad_batches=4, replay_interval=4, grad_norm=2.0, learning_rate=float(g["meta/lr"]),
                                  betas=(0.9, 0.98), weight_decay=0.01, optim="adamw", warmup_steps=int(g["meta/warmup"]),
                                  total_steps=int(g["meta/total_steps"]))
-    tr = Trainer(model, fd, conf, task_id=1)
+    tr = Trainer(model, fd, conf, task_id=1, pipeline_optimizer=pipeline)
+    assert tr.pipeline_optimizer == pipeline
     branches, losses, gns, lrs, sums = [], [], [], [], []
     for bi in range(8):
         batch = R.make_batch(cfg, t["B"], t["T"], seed=seed + 10 + bi, pad=True, n_answer=3)
@@ -192,12 +196,18 @@ def test_trainer_sequence_vs_reference_golden():
         if rec["stepped"]:
             gns.append(float(rec["grad_norm"]))
             lrs.append(rec["lr"])
-            sums.append(float(sum(p.detach().double().sum() for p in model.parameters())))
+            if pipeline and bi == 3:
+                assert model._param_events is not None  # left for the next forward to consume chunk by chunk
+            else:
+                tr.join()
+                sums.append(float(sum(p.detach().double().sum() for p in model.parameters())))
+                assert float(model.flat_grads.abs().max()) == 0.0
     assert branches == list(g["seq/branch"].astype(int))
     close(np.array(losses), g["seq/loss"], TOL, "loss sequence")
     close(np.array(gns), g["seq/grad_norm"], TOL, "grad-norm sequence")
     close(np.array(lrs), g["seq/lr"], 1e-9, "lr sequence")
-    close(np.array(sums), g["seq/checksum"], 1e-5, "parameter checksum after each optimiser step")
+    close(np.array(sums), g["seq/checksum"][-len(sums):], 1e-5, "parameter checksum after each optimiser step")
+    tr.join()
     close(model._p("gpt_neox.final_layer_norm.weight"), g["final/gpt_neox.final_layer_norm.weight"], 1e-4, "final LN weight")
 
 
