@@ -34,7 +34,7 @@ def _build(cfg, sd, dtype=torch.float32):
     return m
 
 
-def _make(cfg, sd, tsd, ddp, rank_batches):
+def _make(cfg, sd, tsd, ddp, rank_batches, pipeline=False):
     from mafed_amd import FeatureDistillation, Trainer
     t = TINY["m64"]
     model, teacher = _build(cfg, sd), _build(cfg, tsd)
@@ -47,7 +47,7 @@ def _make(cfg, sd, tsd, ddp, rank_batches):
     fd.num_vision_tokens = cfg.num_vision_tokens
     conf = types.SimpleNamespace(accumulate_grad_batches=2, replay_interval=2, grad_norm=2.0, learning_rate=1e-3, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_steps=1, total_steps=10)
-    tr = Trainer(model, fd, conf, task_id=1, ddp=ddp, bucket_mb=0.05)
+    tr = Trainer(model, fd, conf, task_id=1, ddp=ddp, bucket_mb=0.05, pipeline_optimizer=pipeline)
     return model, fd, tr
 
 
@@ -56,7 +56,7 @@ def _batches(cfg, rank):
     return [{k: v.cuda() for k, v in R.make_batch(cfg, t["B"], t["T"], seed=100 + 10 * rank + i, pad=True, n_answer=3).items()} for i in range(4)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pipeline=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
@@ -65,7 +65,7 @@ def _worker(rank, world, port, q):
         cfg = tiny_cfg("m64")
         sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
         tsd = R.perturb(sd, seed=22, std=5e-3)
-        model, fd, tr = _make(cfg, sd, tsd, True, None)
+        model, fd, tr = _make(cfg, sd, tsd, True, None, pipeline=pipeline)
         bs = _batches(cfg, rank)
         gns = []
         for i in range(4):  # accumulate 2, replay every 2nd micro-batch: two optimiser steps
@@ -73,6 +73,7 @@ def _worker(rank, world, port, q):
             rec = tr.step(dict(bs[i]), i)
             if rec["stepped"]:
                 gns.append(float(rec["grad_norm"]))
+        tr.join()
         torch.cuda.synchronize()
         q.put((rank, gns, model.flat_params.detach().cpu().numpy()))
     finally:
@@ -80,12 +81,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_ddp_step_equals_mean_of_rank_gradients():
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_ddp_step_equals_mean_of_rank_gradients(pipeline):
+    """pipeline=True: the ranks run Trainer(pipeline_optimizer=True) (AdamW chunks on their own stream behind the bucket
+    all-reduces, next forward waiting per layer) -- what bench.py launches at N > 1."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, pipeline)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
