@@ -319,15 +319,16 @@ __device__ __forceinline__ void load_chunk_rot8(const T* __restrict__ row, int c
   for (int e = 0; e < 8; ++e) o[e] = first ? o[e] * cp[e] - y[e] * sp[e] : o[e] * cp[e] + y[e] * sp[e];
 }
 
-template <typename T>
+template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_decode_block_kernel(const T* __restrict__ qkv_pre, int S0, const T* __restrict__ qkv_new, int cap, int t,
-                                                                int H, int D, int rot, int P, int Tm, const float* __restrict__ rc,
+                                                                int H, int rot, int P, int Tm, const float* __restrict__ rc,
                                                                 const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                                 T* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // q[D] | sc[nk] | red[groups][D] | 8 reduction slots
+  constexpr int chunks = D / 8, groups = 256 / chunks;
   const int tid = threadIdx.x;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int nk = S0 + t + 1, chunks = D >> 3, groups = 256 / chunks;
+  const int nk = S0 + t + 1;
   float* q = lds;
   float* sc = q + D;
   float* red = sc + ((nk + 3) & ~3);
@@ -348,13 +349,14 @@ __global__ __launch_bounds__(256) void attn_decode_block_kernel(const T* __restr
     float s = -INFINITY;
     if (j >= S0 || key_valid(am, b, j, P, Tm)) {
       const T* kp = (j < S0 ? pre + (int64_t)j * rstride : neu + (int64_t)(j - S0) * rstride) + D;
-      float acc = 0.f;
-      for (int c = 0; c < chunks; ++c) {
-        float kv[8];
-        load_chunk_rot8<T>(kp, c, rot, rc, rs, j, kv);
+      float kv[chunks][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], kv[e], acc);
-      }
+      for (int c = 0; c < chunks; ++c) load_chunk_rot8<T>(kp, c, rot, rc, rs, j, kv[c]);  // the whole row in flight at once
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < chunks; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], kv[c][e], acc);
       s = acc * scale;
     }
     sc[j] = s;
@@ -370,21 +372,32 @@ __global__ __launch_bounds__(256) void attn_decode_block_kernel(const T* __restr
   l = block_sum<256>(l, sm);  // (the barriers inside also publish sc[])
   const int c = tid % chunks, kg = tid / chunks;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (kg < groups) {
-    for (int j = kg; j < nk; j += groups) {
-      const T* vp = (j < S0 ? pre + (int64_t)j * rstride : neu + (int64_t)(j - S0) * rstride) + 2 * D + c * 8;
-      float v[8];
-      load_row8<T>(vp, v);
-      const float p = sc[j];
+  auto vrow = [&](int j) { return (j < S0 ? pre + (int64_t)j * rstride : neu + (int64_t)(j - S0) * rstride) + 2 * D + c * 8; };
+  int j = kg;
+  for (; j + 3 * groups < nk; j += 4 * groups) {  // four V rows in flight per thread
+    float v[4][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[e], acc[e]);
+    for (int u = 0; u < 4; ++u) load_row8<T>(vrow(j + u * groups), v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float p = sc[j + u * groups];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[u][e], acc[e]);
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[kg * D + c * 8 + e] = acc[e];
   }
+  for (; j < nk; j += groups) {
+    float v[8];
+    load_row8<T>(vrow(j), v);
+    const float p = sc[j];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[kg * D + c * 8 + e] = acc[e];
   __syncthreads();
   if (tid < D) {
     float o = 0.f;
+#pragma unroll 8
     for (int g2 = 0; g2 < groups; ++g2) o += red[g2 * D + tid];
     Elem<T>::store(out + (int64_t)b * H * D + (int64_t)h * D + tid, o / l);
   }
@@ -393,13 +406,20 @@ __global__ __launch_bounds__(256) void attn_decode_block_kernel(const T* __restr
 template <typename T>
 int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
                        const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st) {
-  if (rot % 16 == 0 && D % 8 == 0 && D <= 256) {
+  if (rot % 16 == 0 && (D == 64 || D == 128 || D == 256)) {
     const int nk = S0 + t + 1, groups = 256 / (D / 8);
     const size_t lb = ((size_t)D + ((nk + 3) & ~3) + (size_t)groups * D + 8) * sizeof(float);
     if (lb <= 160 * 1024) {
-      auto kb = attn_decode_block_kernel<T>;
-      if (lb > 64 * 1024) (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-      kb<<<dim3(H, B), dim3(256), lb, st>>>((const T*)qkv_pre, S0, (const T*)qkv_new, cap, t, H, D, rot, P, Tm, rc, rs, am, (T*)out);
+#define GO(DV)                                                                                                                      \
+  do {                                                                                                                              \
+    auto kb = attn_decode_block_kernel<T, DV>;                                                                                      \
+    if (lb > 64 * 1024) (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);            \
+    kb<<<dim3(H, B), dim3(256), lb, st>>>((const T*)qkv_pre, S0, (const T*)qkv_new, cap, t, H, rot, P, Tm, rc, rs, am, (T*)out);   \
+  } while (0)
+      if (D == 64) GO(64);
+      else if (D == 128) GO(128);
+      else GO(256);
+#undef GO
       return MAFED_OK;
     }
   }
