@@ -64,8 +64,8 @@ class EWC(CLStrategy):
                 wimportances.flat.add_(self.fisher[0].flat, alpha=self.online_factor)  # new + factor * old (ewc.py:60-61)
                 self.fisher[0] = wimportances
             else:
-                for k in self.fisher[0]:
-                    self.fisher[0][k] = wimportances[k] + self.online_factor * self.fisher[0][k]
+                prev = self.fisher[0]
+                self.fisher[0] = {k: v.add(prev[k], alpha=self.online_factor) for k, v in wimportances.items()}
             self.old_params[0] = prev_w
         else:
             self.fisher[self.task_id] = wimportances
@@ -77,41 +77,38 @@ class EWC(CLStrategy):
         model.train()
         native = hasattr(model, "flat_params")
         if native:
-            imp = torch.zeros_like(model.flat_params)
-        else:
-            importances = {k: torch.zeros_like(p) for k, p in model.named_parameters() if p.requires_grad}
-        total_samples = 0.0
+            acc = torch.zeros_like(model.flat_params)
+        else:  # foreign nn.Module: one multi-tensor op per batch over the trainable tensors
+            names, params = zip(*[(k, p) for k, p in model.named_parameters() if p.requires_grad])
+            acc = [torch.zeros_like(p) for p in params]
+        seen = 0.0
         for batch in dataloader:
             model.zero_grad()
-            batch_size = batch["input_ids"].size(0)
-            loss = batch_size * model(**batch, compute_loss=True, return_dict=True).loss
-            loss.backward()
+            n = batch["input_ids"].size(0)
+            (n * model(**batch, compute_loss=True, return_dict=True).loss).backward()
             if native:
-                imp.addcmul_(model.flat_grads, model.flat_grads)
+                acc.addcmul_(model.flat_grads, model.flat_grads)
             else:
-                for k, p in model.named_parameters():
-                    if p.grad is not None:
-                        importances[k] += p.grad.data.clone().pow(2)
-            total_samples += batch_size
+                live = [(a, p.grad) for a, p in zip(acc, params) if p.grad is not None]
+                torch._foreach_addcmul_([a for a, _ in live], [g for _, g in live], [g for _, g in live])
+            seen += n
         model.zero_grad()
         if native:
-            imp.div_(total_samples)
-            return _FlatDict(model, imp)
-        for k in importances:
-            importances[k] /= total_samples
-        return importances
+            return _FlatDict(model, acc.div_(seen))
+        torch._foreach_div_(acc, seen)
+        return dict(zip(names, acc))
 
     # inside a step ---------------------------------------------------------------------------------------------------
     def compute_regularization(self, model, loss, task_id):
         fisher, old = self.fisher[task_id], self.old_params[task_id]
         if hasattr(model, "flat_params") and isinstance(fisher, _FlatDict) and model.flat_params.is_cuda:
             return loss + _EwcPenaltyFn.apply(model._anchor, model, old.flat, fisher.flat, float(self.reg_lambda))
-        for k, cur_param in model.named_parameters():
-            if not cur_param.requires_grad:
-                continue
-            diff = (cur_param - old[k]).pow(2)
-            loss = loss + 0.5 * self.reg_lambda * (fisher[k] * diff).sum()
-        return loss
+        # foreign nn.Module: 0.5 * lambda * sum_k <F_k, (p_k - p*_k)^2> with multi-tensor ops (ewc.py:105-115)
+        keys = [k for k, p in model.named_parameters() if p.requires_grad]
+        cur = [dict(model.named_parameters())[k] for k in keys]
+        delta = torch._foreach_sub(cur, [old[k] for k in keys])
+        weighted = torch._foreach_mul(torch._foreach_mul(delta, delta), [fisher[k] for k in keys])
+        return loss + 0.5 * self.reg_lambda * torch.stack([w.sum() for w in weighted]).sum()
 
     def compute_loss(self, model, loss, **kwargs):
         if self.task_id == 0:

@@ -165,3 +165,51 @@ def test_hbm_replay_buffer_and_memory_update():
     expect = np.random.default_rng(42).choice(np.arange(20), 5, replace=False)
     got = fd.datasets[0]["input_ids"]
     assert torch.equal(got, data["input_ids"][torch.as_tensor(np.sort(expect))])
+
+
+def test_ewc_foreign_module_path_matches_oracle():
+    """CLMethod["ewc"] on a plain nn.Module (no flat buffers, CPU): importances, online update and penalty through the
+    multi-tensor route against the oracle formulas."""
+    import torch
+    from mafed_amd import CLMethod
+    from oracle import vlpythia_ref as R
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.a = torch.nn.Linear(5, 7)
+            self.b = torch.nn.Linear(7, 3)
+
+        def forward(self, input_ids, compute_loss=True, return_dict=True, **kw):
+            x = torch.nn.functional.one_hot(input_ids % 5, 5).float().mean(1)
+            out = self.b(torch.tanh(self.a(x)))
+            return type("O", (), {"loss": out.pow(2).mean()})()
+
+    m = Tiny()
+    loader = [{"input_ids": torch.arange(12).reshape(4, 3) + i} for i in range(3)]
+    ewc = CLMethod["ewc"](reg_lambda=7.0, online=True, online_factor=0.9)
+    ewc.update(model=m, dataloader=loader)
+    want = {k: torch.zeros_like(p) for k, p in m.named_parameters()}
+    for b in loader:
+        m.zero_grad()
+        (4 * m(**b).loss).backward()
+        for k, p in m.named_parameters():
+            want[k] += p.grad.pow(2)
+    for k in want:
+        assert torch.allclose(ewc.fisher[0][k], want[k] / 12.0, rtol=1e-6, atol=1e-9)
+    old = {k: p.detach().clone() for k, p in m.named_parameters()}
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01)
+    base = torch.tensor(1.5)
+    got = ewc.compute_loss(m, base)
+    ref = base + R.ewc_penalty(dict(m.named_parameters()), old, ewc.fisher[0], 7.0)
+    assert torch.allclose(got, ref, rtol=1e-6)
+    got.backward()
+    assert all(p.grad is not None for p in m.parameters())
+    ewc.update(model=m, dataloader=loader)   # task_id 1: overwrite
+    f1 = {k: v.clone() for k, v in ewc.fisher[0].items()}
+    ewc.update(model=m, dataloader=loader)   # task_id 2: new + 0.9 * old
+    for k in f1:
+        assert torch.allclose(ewc.fisher[0][k], f1[k] * 1.9, rtol=1e-5)
