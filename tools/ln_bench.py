@@ -37,3 +37,16 @@ for inject in (False, True):
         best = min(best, e0.elapsed_time(e1) / 20)
     mb = rows * h * (4 + 2 + 2 + 4 + 4 + 2 + (4 if inject else 0)) / 1e6
     print(f"layernorm_bwd dual{' + injection' if inject else ''}: {best * 1e3:6.1f} us  ({mb / best / 1e3:5.2f} TB/s algorithmic)", flush=True)
+
+
+b1, b2 = rn(h), rn(h)
+best = 1e9
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.layernorm_fwd(x, w1, b1, w2, b2, 1e-5, torch.bfloat16, save_stats=True)
+    e1.record()
+    torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) / 20)
+print(f"layernorm_fwd dual: {best * 1e3:6.1f} us  ({rows * h * (4 + 2 + 2) / 1e6 / best / 1e3:5.2f} TB/s algorithmic)", flush=True)
