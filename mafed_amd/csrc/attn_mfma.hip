@@ -695,14 +695,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
           }
         }
       } else {
+        // plain tile: the scale is folded into the exponent's FMA below; the maximum commutes with the positive scale
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = s[j][r] * scale2;
-            s[j][r] = v;
-            tmax = fmaxf(tmax, v);
-          }
+          for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[j][r]);
+        tmax *= scale2;
       }
       tmax = col_max_sw(tmax);
       // Lazy rescale: the running reference m only moves when some row's maximum outgrew it by more than 2^8 (exact
@@ -721,7 +719,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[j][r] - m);
+          const float pv = __builtin_amdgcn_exp2f(MASK ? s[j][r] - m : fmaf(s[j][r], scale2, -m));
           s[j][r] = pv;
           ps += pv;
         }
