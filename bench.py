@@ -8,10 +8,21 @@ cached inside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model 410m] [--batch 32] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+``python bench.py --gpus N`` without a launcher starts the N ranks itself (a torch.distributed.run child, before anything touches
+the GPU) and fails if the node has fewer than N GPUs or fewer than N ranks join -- it never reports a 1-GPU number for N > 1.
+
+The JSON line carries, beside the contract's keys: ``roofline`` (dominant kernel = the bf16 MFMA GEMM: algorithmic flops / the
+kernel's own execution time inside the step, measured live with start/stop events on the launches -- the quantity rocprofv3
+--kernel-trace reports, see profiles/), ``kernels`` (the same for attention and for every HBM-bound kernel against 8 TB/s),
+``secondary`` (the reference's blended schedule: bs 16 x accumulate 4, 3 plain-CE + 1 MAFED micro-batch per optimiser step,
+scripts/run_seed42.sh:51-70) and ``cpu_baseline``.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -78,6 +89,23 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
             "sample": f"oracle fp32 CPU, VLPythia-{model_name}+MAFED distill step, batch {B} (of 32), {P} img + {T} txt tokens, {n} timed steps"}
 
 
+def _spawn_ranks(n: int) -> int:
+    """``--gpus n`` outside a launcher: become the launcher.  Runs before any HIP call in this process (device_count() does
+    not initialise the GPU on this image) and hands the child's exit code back."""
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,31 +117,46 @@ def main():
     ap.add_argument("--txt-tokens", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gemm-events", action="store_true")
-    ap.add_argument("--graphs", action="store_true", help="replay the step from a hipGraph (measured slower than eager launches on ROCm 7: 42.9 vs 39.7 ms)")
-    ap.add_argument("--no-graphs", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel roofline steps after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the blended-schedule measurement (3 CE + 1 MAFED micro-batches)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
+    ap.add_argument("--reduce-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the links")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
     args = ap.parse_args()
 
-    from mafed_amd import FeatureDistillation, Trainer, VLPythiaConfig, VLPythiaForCausalLM, ops
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus))
+
+    from mafed_amd import FeatureDistillation, Trainer, VLPythiaConfig, VLPythiaForCausalLM
     from mafed_amd.dist import broadcast_teacher, init_from_env
     from mafed_amd.methods import HBMReplayBuffer
+    from mafed_amd.profiler import KernelProfile
     import torch.distributed as dist
 
     if args.gemm_variant is not None:
         from mafed_amd import _lib
         _lib.load().mafed_gemm_set_variant(args.gemm_variant)
     rank, local, world = init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (mafed_amd has no CPU path)")
+    ranks_joined = dist.get_world_size() if world > 1 else 1
+    if ranks_joined != args.gpus:
+        raise SystemExit(f"bench.py: {ranks_joined} ranks joined the process group, {args.gpus} requested")
+    backend = dist.get_backend() if world > 1 else None
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node exposes {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, P, T = args.batch, args.img_tokens, args.txt_tokens
     cfg = VLPythiaConfig.preset(args.model, num_vision_tokens=P)
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    gdt = torch.bfloat16 if args.grad_dtype == "bf16" else None
 
     # synthetic inputs of SURVEY.md section 8d: weights N(0, 0.02) (HF init), teacher = student + N(0, 1e-3)
     student = VLPythiaForCausalLM(cfg, compute_dtype=cd, device=dev, seed=1234)
@@ -136,14 +179,15 @@ def main():
     ids = torch.randint(1, cfg.vocab_size, (n_mem, T), generator=gcpu)
     labels = torch.full((n_mem, T), -100, dtype=torch.int64)
     labels[:, -4:] = ids[:, -4:]
+    mem_samples = {"input_ids": ids, "attention_mask": torch.ones(n_mem, T, dtype=torch.int64), "labels": labels,
+                   "patch_embeddings": torch.randn(n_mem, P, cfg.vision_hidden_size, generator=torch.Generator().manual_seed(1234 + rank))}
     mem = HBMReplayBuffer(B, dev, seed=1236 + rank)
-    mem.add({"input_ids": ids, "attention_mask": torch.ones(n_mem, T, dtype=torch.int64), "labels": labels,
-             "patch_embeddings": torch.randn(n_mem, P, cfg.vision_hidden_size, generator=torch.Generator().manual_seed(1234 + rank))})
+    mem.add(mem_samples)
     fd.mem_dataloader = mem
     conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=1, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_perc=0.1)
-    tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, use_graphs=args.graphs and not args.no_graphs,
-                 pipeline_optimizer=not args.no_pipeline_optimizer)
+    tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
+                 bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt)
     task_batch = mem.sample()  # dropped by a replay step, as in the reference
 
     def barrier():
@@ -154,7 +198,7 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    log(f"setup done: {args.model} B={B} P={P} T={T} dtype={args.dtype} world={world}")
+    log(f"setup done: {args.model} B={B} P={P} T={T} dtype={args.dtype} world={world} backend={backend}")
     for i in range(args.warmup):
         tw = time.perf_counter()
         tr.step(task_batch, i)
@@ -162,7 +206,6 @@ def main():
         log(f"warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     torch.cuda.synchronize()
     barrier()
-    log(f"graph replay: {bool(tr._graphs)}")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -179,56 +222,113 @@ def main():
     log(f"timed region: {args.steps} steps in {dt * 1e3:.1f} ms (host enqueue {t_host * 1e3:.1f} ms), loss {loss:.5f}")
     assert loss == loss, "NaN loss in the timed region"
 
-    # live roofline of the dominant kernel: two more steps, launched eagerly so that every bf16 MFMA GEMM launch can be
-    # bracketed by HIP events on its own stream (same kernels, same streams/overlap as the replayed graph; not part of `value`)
-    # (every rank takes these steps -- they contain the gradient all-reduce -- but only rank 0 records events)
-    ev_alone = None
-    if not args.no_gemm_events:
-        graphs_on = tr.use_graphs
-        tr.use_graphs = False
-        ops.GEMM_EVENTS = [] if rank == 0 else None
-        for i in range(2):
-            tr.step(task_batch, args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        ev_overlapped, ops.GEMM_EVENTS = ops.GEMM_EVENTS, ([] if rank == 0 else None)
-        # ... and two steps with the side streams switched off (dW GEMMs and the teacher forward in line on the main
-        # stream): every GEMM then has the chip to itself, which is the number a per-kernel roofline should be read against
-        ov = (student.overlap_param_grads, fd.overlap_teacher)
-        student.overlap_param_grads, fd.overlap_teacher = False, False
-        for i in range(2):
-            tr.step(task_batch, args.warmup + args.steps + 2 + i)
-        torch.cuda.synchronize()
-        student.overlap_param_grads, fd.overlap_teacher = ov
-        ev_alone, ops.GEMM_EVENTS = ops.GEMM_EVENTS, ev_overlapped
-        tr.use_graphs = graphs_on
+    # live rooflines: N_PROF more steps of the SAME configuration (same streams / overlap) with every hot kernel launched
+    # between a start/stop event pair: per-kernel execution time, as rocprofv3 --kernel-trace would report it.  Not part of
+    # `value`.  Every rank takes these steps (they contain the gradient collectives); rank 0 reports.
+    N_PROF = 3
+    prof_step, prof_alone = None, None
+    if not args.no_kernel_profile:
+        with KernelProfile() as kp:
+            for i in range(N_PROF):
+                tr.step(task_batch, args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+        prof_step = kp.summary()
+        # ... and once more with the side streams switched off (dW GEMMs, teacher forward and the optimiser in line on one
+        # stream): every kernel then has the chip to itself -- what a per-kernel roofline is read against
+        ov = (student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer)
+        tr.join()
+        student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer = False, False, False
+        with KernelProfile() as kp1:
+            for i in range(N_PROF):
+                tr.step(task_batch, args.warmup + args.steps + N_PROF + i)
+            torch.cuda.synchronize()
+        prof_alone = kp1.summary()
+        student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer = ov
         barrier()
+
+    # secondary metric: the reference's blended schedule -- bs 16 x accumulate 4, replay_interval 4: per optimiser
+    # step three plain-CE micro-batches on task data and one MAFED micro-batch on memory data (scripts/run_seed42.sh:51-70)
+    secondary = None
+    if not args.no_secondary:
+        tr.join()
+        B2 = 16
+        mem2 = HBMReplayBuffer(B2, dev, seed=2236 + rank)
+        mem2.add(mem_samples)
+        fd.mem_dataloader = mem2
+        fd.batch_size = B2
+        conf2 = types.SimpleNamespace(accumulate_grad_batches=4, replay_interval=4, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
+                                      weight_decay=0.01, optim="adamw", warmup_perc=0.1)
+        student.zero_grad()
+        tr2 = Trainer(student, fd, conf2, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
+                      bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt)
+        task2 = [mem2._draw() for _ in range(4)]   # current-task micro-batches (synthetic, resident in HBM)
+        n_opt = max(3, args.steps // 4)
+        for i in range(8):                          # two untimed optimiser steps
+            tr2.step(task2[i % 4], i)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(4 * n_opt):
+            rec2 = tr2.step(task2[i % 4], 8 + i)
+        torch.cuda.synchronize()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        t2 = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dt2 = float(t2.item())
+        tr2.join()
+        fl2 = B2 * (3 * algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size, distill=False)
+                    + algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size, distill=True))
+        secondary = {"metric": "train samples/s, reference schedule: bs16 x accum4, 3 plain-CE + 1 MAFED micro-batch per optimiser step",
+                     "value": round(4 * B2 * n_opt * world / dt2, 3), "unit": "samples/s", "optimizer_steps": n_opt,
+                     "ms_per_optimizer_step": round(dt2 / n_opt * 1e3, 3), "samples_per_optimizer_step": 4 * B2 * world,
+                     "mfma_frac_whole_step": round(fl2 * n_opt / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(rec2["loss"]), 5)}
+        log(f"secondary: {n_opt} optimiser steps in {dt2 * 1e3:.1f} ms")
+
     if rank == 0:
         samples = args.steps * B * world
         value = samples / dt
         flops_step = algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size) * B
-        roof = None
-        if ops.GEMM_EVENTS:
-            ev = ops.GEMM_EVENTS
-            ops.GEMM_EVENTS = None
-            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
-            fl = sum(f for _, _, f in ev)
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
-            try:  # HBM-side bytes per launch of this kernel from the committed PMC run (FETCH_SIZE x2-corrected + WRITE_SIZE)
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
-                    traffic = json.load(fp)["hbm_MB_per_launch"] * 1e6
-            except Exception:
-                pass
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch of 2 more steps run right after the timed region)",
-                    "launches": len(ev), "avg_launch_us": round(ms * 1e3 / len(ev), 2), "avg_gflop_per_launch": round(fl / len(ev) / 1e9, 3),
-                    "note": "launch durations overlap: dW GEMMs and the teacher forward run on side streams"}
-            if ev_alone:
-                ms1 = sum(a.elapsed_time(b) for a, b, _ in ev_alone)
-                ach1 = sum(f for _, _, f in ev_alone) / (ms1 * 1e-3) / 1e12
-                roof["achieved_no_overlap"] = round(ach1, 2)
-                roof["frac_no_overlap"] = round(ach1 / PEAK_BF16_TFLOPS, 4)
-                roof["avg_launch_us_no_overlap"] = round(ms1 * 1e3 / len(ev_alone), 2)
+        roof, kernels = None, None
+        if prof_step and "gemm_bf16" in prof_step:
+            gm = prof_step["gemm_bf16"]
+            traffic, tsrc = None, None
+            for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:  # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE)
+                    with open(os.path.join(ROOT, "profiles", cand)) as fp:
+                        traffic = json.load(fp)["hbm_MB_per_launch"] * 1e6
+                    tsrc = f"profiles/{cand} (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+                    break
+                except Exception:
+                    pass
+            roof = {"bound": "mfma", "achieved": round(gm["achieved"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(gm["frac"], 4), "traffic": traffic, "traffic_source": tsrc,
+                    "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch)",
+                    "mode": f"sum(2MNK) / sum(kernel execution time) over {N_PROF} steps of the timed configuration (side streams on: kernels "
+                            "share the chip), start/stop events on each launch = rocprofv3 --kernel-trace durations",
+                    "launches_per_step": round(gm["launches"] / N_PROF, 1), "avg_launch_us": round(gm["avg_us"], 2),
+                    "avg_gflop_per_launch": round(gm["work"] / gm["launches"] / 1e9, 3)}
+            if prof_alone and "gemm_bf16" in prof_alone:
+                g1 = prof_alone["gemm_bf16"]
+                roof["achieved_no_overlap"] = round(g1["achieved"], 2)
+                roof["frac_no_overlap"] = round(g1["frac"], 4)
+                roof["avg_launch_us_no_overlap"] = round(g1["avg_us"], 2)
+            kernels = []
+            for tag in ("gemm_bf16", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "layernorm_fwd", "layernorm_bwd", "ce_fwd", "ce_bwd", "distill_fwd",
+                        "adamw", "gradnorm", "embed_concat_fwd", "embed_concat_bwd", "cast", "colsum", "layernorm_bwd_reduce"):
+                a = prof_step.get(tag)
+                if not a:
+                    continue
+                e = {"kernel": tag, "bound": a["bound"], "launches_per_step": round(a["launches"] / N_PROF, 1), "avg_us": round(a["avg_us"], 2),
+                     "ms_per_step": round(a["total_ms"] / N_PROF, 3),
+                     ("gflop_per_launch" if a["bound"] == "mfma" else "MB_per_launch"): round(a["work"] / a["launches"] / (1e9 if a["bound"] == "mfma" else 1e6), 3),
+                     "achieved": round(a["achieved"], 1), "unit": a["unit"], "peak": a["peak"], "frac": round(a["frac"], 4)}
+                a1 = prof_alone.get(tag) if prof_alone else None
+                if a1:
+                    e["avg_us_no_overlap"] = round(a1["avg_us"], 2)
+                    e["frac_no_overlap"] = round(a1["frac"], 4)
+                kernels.append(e)
         out = {"metric": "train samples/sec VLPythia-410M+MAFED, 256img+32txt tok, bs=32, 1/2/4/8 GPU" if args.model == "410m" else
                f"train samples/sec VLPythia-{args.model}+MAFED", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -237,10 +337,18 @@ def main():
                           f"{cfg.num_hidden_layers - 1}-layer per-modality MSE, clip 2.0, AdamW), {P} img + {T} txt tokens",
                           "global_batch": B * world, "per_gpu_batch": B, "seq_len": P + T, "parallelism": f"dp{world}",
                           "random_init_weights": True},
+               "ranks_joined": ranks_joined, "dist_backend": backend,
                "step_tflops_algorithmic": round(flops_step / 1e12, 3),
                "mfma_frac_whole_step": round(flops_step * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5)}
+        if world > 1:
+            out["grad_exchange"] = {"mode": args.reduce_mode, "dtype": args.grad_dtype, "bucket_mb": args.bucket_mb,
+                                    "MB_per_step": round(tr.reducer.bytes_per_step / 1e6, 1), "buckets": len(tr.reducer.buckets)}
         if roof:
             out["roofline"] = roof
+        if kernels:
+            out["kernels"] = kernels
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model, P, T)

@@ -216,6 +216,19 @@ int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype ds
 /* y = gelu_erf(x) elementwise (used by tests; the product path fuses GELU into mafed_gemm) */
 int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream);
 
+/* ---- measurement: per-kernel execution time of the launches this library makes --------------------------------------
+ * No reference counterpart (the reference has no profiling); bench.py's `roofline` / `kernels` come from here.
+ * Between mafed_prof_begin(max_records) and mafed_prof_end() every hot kernel is launched with a start/stop event pair
+ * (hipExtLaunchKernelGGL): the elapsed time of a pair is that dispatch's own execution time on the GPU -- what
+ * `rocprofv3 --kernel-trace` reports -- independent of how long the launch sat queued behind other streams.  After the caller
+ * has synchronised the device, mafed_prof_collect() returns, in launch order, each record's kernel tag, its algorithmic work
+ * (flops for the MFMA kernels, bytes for the HBM-bound ones) and its duration in ms (host pointers),
+ * and the number of records held.  mafed_prof_tag_name() names a tag.  Launches beyond max_records are not recorded. */
+int mafed_prof_begin(int max_records);
+int mafed_prof_end(void);
+int mafed_prof_collect(int* tags_host, double* work_host, float* ms_host, int max);
+const char* mafed_prof_tag_name(int tag);
+
 /* test / tuning hook: 0 = automatic kernel choice, 1 = force the register-staged MFMA GEMM (the ragged-shape kernel),
  * 10 + c = force LDS-DMA tile configuration c; 100 = automatic split-K for accumulate-only outputs, 101 = no split-K,
  * 100 + n = force n K-splits where legal */

@@ -53,6 +53,10 @@ SIGNATURES = {
     "mafed_optim_advance": (_i, [_p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_gelu": (_i, [_p, _p, _i, _l, _p]),
+    "mafed_prof_begin": (_i, [_i]),
+    "mafed_prof_end": (_i, []),
+    "mafed_prof_collect": (_i, [_p, _p, _p, _i]),
+    "mafed_prof_tag_name": (C.c_char_p, [_i]),
 }
 
 _lib: Optional[C.CDLL] = None

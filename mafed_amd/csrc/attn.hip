@@ -12,7 +12,7 @@ static int check_common(const char* who, const void* qkv, int B, int S, int H, i
   return MAFED_OK;
 }
 
-static bool mfma_ok(int D, int rot) { return (D == 64 || D == 128) && (rot == 0 || rot == 16 || rot == 32 || rot == 64) && rot * 2 <= D * 2; }
+static bool mfma_ok(int D, int rot) { return (D == 64 || D == 128 || D == 256) && (rot == 0 || rot == 16 || rot == 32 || rot == 64) && rot * 2 <= D * 2; }
 
 extern "C" int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, int H, int D, int rot, const float* rot_cos,
                               const float* rot_sin, const int64_t* attention_mask, int T, void* out, float* lse, void* stream) {
@@ -29,7 +29,7 @@ extern "C" int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, 
     rc = attn_mfma_fwd_launch(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, st);
   } else {
     MAFED_CHECK_ARG(D <= 256, "attn_fwd(bf16): D=%d > 256", D);
-    rc = attn_ref_fwd_launch<bf16_t>(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, st);  // head sizes without an MFMA kernel yet
+    rc = attn_ref_fwd_launch<bf16_t>(qkv, sh, rot_cos, rot_sin, attention_mask, out, lse, st);  // head sizes other than 64 / 128 / 256
   }
   if (rc) return rc;
   MAFED_CHECK_LAUNCH("attn_fwd");

@@ -23,7 +23,11 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 template <int D>
 __device__ __forceinline__ int tile_off(int row, int chunk) {
   if (D == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-  return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+  if (D == 128) return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+  // D = 256 (VLPythia-1B): 512-byte rows, the low four chunk bits XORed with f(row) = (row & 7) << 1 | (row >> 3) & 1 -- a bijection
+  // on every aligned group of 16 rows (row reads of one chunk hit 16 distinct 16-byte slots) whose upper three bits differ over
+  // every aligned group of 8 rows (the 8 x 32-byte pieces of a transposing read hit 8 distinct 32-byte slots)
+  return row * 512 + ((chunk ^ (((row & 7) << 1) | ((row >> 3) & 1))) << 4);
 }
 
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
@@ -232,7 +236,7 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
                                                             const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                             bf16_t* __restrict__ out, float* __restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * 64 * D * 2 bytes (64 KiB at D = 256)
   char* kimg = lds;
   char* vimg = lds + 64 * D * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
                                                                const float* __restrict__ rc, const float* __restrict__ rs,
                                                                const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
                                                                float* __restrict__ delta) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * 64 * D * 2 bytes
   char* kimg = lds;
   char* vimg = lds + 64 * D * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
                                                                 const float* __restrict__ lse, const float* __restrict__ delta, AttnShape sh,
                                                                 const float* __restrict__ rc, const float* __restrict__ rs,
                                                                 const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2 + 2 * 64 * 4];
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 * 64 * D * 2 + 2 * 64 * 4 bytes
   char* qimg = lds;
   char* doimg = lds + 64 * D * 2;
   float* Ls = reinterpret_cast<float*>(lds + 2 * 64 * D * 2);
@@ -1054,10 +1058,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
   }
 }
 
+// algorithmic forward flops of one launch: QK^T and PV over the causal half, 4 D S (S + 1) / 2 per (batch, head);
+// the backward's 2x is booked half on the dQ kernel (dP, dQ) and half on the dK/dV kernel (dK, dV)
+static double attn_fwd_flops(const AttnShape& sh) { return 4.0 * sh.D * ((double)sh.S * (sh.S + 1) / 2.0) * sh.H * sh.B; }
+
 static bool attn_resident_fits(const AttnShape& sh, size_t* bytes) {
   const size_t nrows = (size_t)(sh.S + 31) / 32 * 32;
   *bytes = nrows * sh.D * 2 * 2 + nrows * 4 * 2 + (size_t)sh.D * 4 * 2;  // two operand images + two fp32 rows (key bias | LSE, delta) + the column-sum row
-  return *bytes <= 160 * 1024;
+  return sh.D <= 128 && *bytes <= 160 * 1024;  // (D = 256: 295 KiB at S = 288 -- K / V go through LDS in 64-row tiles instead)
 }
 static int g_attn_variant = 0;  // 0 automatic, 1 force the tiled kernels (tests)
 
@@ -1073,16 +1081,24 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
     dim3 grid(sh.H, sh.B), block(256);
     if (sh.D == 64) {
       set_lds_attr(attn_fwd_res_kernel<64>, bytes);
-      attn_fwd_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+      launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_res_kernel<64>, grid, block, bytes, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
     } else {
       set_lds_attr(attn_fwd_res_kernel<128>, bytes);
-      attn_fwd_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+      launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_res_kernel<128>, grid, block, bytes, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
     }
     return MAFED_OK;
   }
   dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
-  if (sh.D == 64) attn_fwd_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
-  else attn_fwd_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+  const size_t tb = (size_t)2 * 64 * sh.D * 2;
+#define MAFED_FWD_TILED(DD)                                                                                                       \
+  do {                                                                                                                            \
+    set_lds_attr(attn_fwd_mfma_kernel<DD>, tb);                                                                                   \
+    launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_mfma_kernel<DD>, grid, block, tb, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);                    \
+  } while (0)
+  if (sh.D == 64) MAFED_FWD_TILED(64);
+  else if (sh.D == 128) MAFED_FWD_TILED(128);
+  else MAFED_FWD_TILED(256);
+#undef MAFED_FWD_TILED
   return MAFED_OK;
 }
 
@@ -1095,29 +1111,34 @@ int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, con
     if (sh.D == 64) {
       set_lds_attr(attn_bwd_dq_res_kernel<64>, bytes);
       set_lds_attr(attn_bwd_dkv_res_kernel<64>, bytes);
-      attn_bwd_dq_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
+      launch(K_ATTN_BWD_DQ, attn_fwd_flops(sh), attn_bwd_dq_res_kernel<64>, grid, block, bytes, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
                                                              (bf16_t*)dqkv, delta, colsum);
-      attn_bwd_dkv_res_kernel<64><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv, colsum);
+      launch(K_ATTN_BWD_DKV, attn_fwd_flops(sh), attn_bwd_dkv_res_kernel<64>, grid, block, bytes, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv, colsum);
     } else {
       set_lds_attr(attn_bwd_dq_res_kernel<128>, bytes);
       set_lds_attr(attn_bwd_dkv_res_kernel<128>, bytes);
-      attn_bwd_dq_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
+      launch(K_ATTN_BWD_DQ, attn_fwd_flops(sh), attn_bwd_dq_res_kernel<128>, grid, block, bytes, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
                                                               (bf16_t*)dqkv, delta, colsum);
-      attn_bwd_dkv_res_kernel<128><<<grid, block, bytes, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv, colsum);
+      launch(K_ATTN_BWD_DKV, attn_fwd_flops(sh), attn_bwd_dkv_res_kernel<128>, grid, block, bytes, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv, colsum);
     }
     *colsum_done = colsum != nullptr;
     return MAFED_OK;
   }
   dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
-  if (sh.D == 64) {
-    attn_bwd_dq_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
-                                                        (bf16_t*)dqkv, delta);
-    attn_bwd_dkv_mfma_kernel<64><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
-  } else {
-    attn_bwd_dq_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am,
-                                                         (bf16_t*)dqkv, delta);
-    attn_bwd_dkv_mfma_kernel<128><<<grid, block, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am, (bf16_t*)dqkv);
-  }
+  const size_t tb = (size_t)2 * 64 * sh.D * 2, tb2 = tb + 2 * 64 * 4;
+#define MAFED_BWD_TILED(DD)                                                                                                       \
+  do {                                                                                                                            \
+    set_lds_attr(attn_bwd_dq_mfma_kernel<DD>, tb);                                                                                \
+    set_lds_attr(attn_bwd_dkv_mfma_kernel<DD>, tb2);                                                                              \
+    launch(K_ATTN_BWD_DQ, attn_fwd_flops(sh), attn_bwd_dq_mfma_kernel<DD>, grid, block, tb, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, sh, rc, rs, am, \
+                                                         (bf16_t*)dqkv, delta);                                                  \
+    launch(K_ATTN_BWD_DKV, attn_fwd_flops(sh), attn_bwd_dkv_mfma_kernel<DD>, grid, block, tb2, st, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, sh, rc, rs, am,   \
+                                                           (bf16_t*)dqkv);                                                       \
+  } while (0)
+  if (sh.D == 64) MAFED_BWD_TILED(64);
+  else if (sh.D == 128) MAFED_BWD_TILED(128);
+  else MAFED_BWD_TILED(256);
+#undef MAFED_BWD_TILED
   return MAFED_OK;
 }
 

@@ -93,10 +93,11 @@ extern "C" int mafed_ce_fwd(const void* logits, mafed_dtype dtype, const int64_t
   MAFED_CHECK_ARG(B > 0 && T > 0 && V > 0 && V % 4 == 0, "ce_fwd: bad shape (V must be a multiple of 4)");
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)((int64_t)B * T)), block(256);
-  if (dtype == MAFED_F32) ce_fwd_kernel<float><<<grid, block, 0, st>>>((const float*)logits, labels, B, T, V, lse, row_loss);
-  else ce_fwd_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)logits, labels, B, T, V, lse, row_loss);
+  const double ce_bytes = (double)B * T * V * (dtype == MAFED_F32 ? 4.0 : 2.0);  // the logits, read once
+  if (dtype == MAFED_F32) launch(K_CE_FWD, ce_bytes, ce_fwd_kernel<float>, grid, block, 0, st, (const float*)logits, labels, B, T, V, lse, row_loss);
+  else launch(K_CE_FWD, ce_bytes, ce_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, labels, B, T, V, lse, row_loss);
   MAFED_CHECK_LAUNCH("ce_fwd");
-  ce_finalize_kernel<<<dim3(1), block, 0, st>>>(row_loss, labels, B, T, V, loss_out);
+  launch(K_SMALL, 0.0, ce_finalize_kernel, dim3(1), block, 0, st, row_loss, labels, B, T, V, loss_out);
   MAFED_CHECK_LAUNCH("ce_fwd(finalize)");
   return MAFED_OK;
 }
@@ -107,8 +108,9 @@ extern "C" int mafed_ce_bwd(const void* logits, mafed_dtype dtype, const int64_t
   MAFED_CHECK_ARG(B > 0 && T > 0 && V > 0 && V % 4 == 0, "ce_bwd: bad shape (V must be a multiple of 4)");
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)((int64_t)B * T)), block(256);
-  if (dtype == MAFED_F32) ce_bwd_kernel<float><<<grid, block, 0, st>>>((const float*)logits, labels, lse, B, T, V, gloss_dev, (float*)dlogits);
-  else ce_bwd_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)logits, labels, lse, B, T, V, gloss_dev, (bf16_t*)dlogits);
+  const double ce_bytes = 2.0 * B * T * V * (dtype == MAFED_F32 ? 4.0 : 2.0);  // logits in, gradient out
+  if (dtype == MAFED_F32) launch(K_CE_BWD, ce_bytes, ce_bwd_kernel<float>, grid, block, 0, st, (const float*)logits, labels, lse, B, T, V, gloss_dev, (float*)dlogits);
+  else launch(K_CE_BWD, ce_bytes, ce_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, labels, lse, B, T, V, gloss_dev, (bf16_t*)dlogits);
   MAFED_CHECK_LAUNCH("ce_bwd");
   return MAFED_OK;
 }

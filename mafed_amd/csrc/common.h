@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels.  wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -26,6 +27,29 @@ void set_error(const char* fmt, ...);
       return MAFED_ELAUNCH;                                                  \
     }                                                                        \
   } while (0)
+
+// ---- in-library kernel profiler (mafed_prof_*, include/mafed_hip.h) ---------------------------------------------------------
+// Every hot kernel goes through launch(): a plain launch normally; while a profile is open the same kernel is launched with
+// hipExtLaunchKernelGGL and a start/stop event pair, whose elapsed time is the kernel's own execution time on the GPU (the
+// dispatch's begin/end timestamps -- what rocprofv3 --kernel-trace reports), not a stream bracket that would also count the
+// time spent queued behind other streams' kernels.  `work` is the launch's algorithmic work in the unit of its roofline:
+// flops for the MFMA kernels (GEMM, attention), bytes for the HBM-bound ones.
+enum KernelTag {
+  K_GEMM_BF16 = 0, K_GEMM_F32, K_GEMM_SKINNY, K_ATTN_FWD, K_ATTN_BWD_DQ, K_ATTN_BWD_DKV, K_ATTN_EXACT, K_LN_FWD, K_LN_BWD, K_LN_BWD_REDUCE,
+  K_CE_FWD, K_CE_BWD, K_DISTILL_FWD, K_DISTILL_BWD, K_ADAMW, K_GRADNORM, K_EMBED_FWD, K_EMBED_BWD, K_COLSUM, K_CAST, K_EWC, K_SMALL, K_TAG_COUNT
+};
+extern bool g_prof_on;
+bool prof_events(int tag, double work, hipEvent_t* e0, hipEvent_t* e1);
+
+template <typename... KArgs, typename... Args>
+inline void launch(int tag, double work, void (*kfn)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+  hipEvent_t e0, e1;
+  if (g_prof_on && prof_events(tag, work, &e0, &e1)) {
+    hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds, st, e0, e1, 0, static_cast<KArgs>(args)...);
+    return;
+  }
+  kfn<<<grid, block, lds, st>>>(static_cast<KArgs>(args)...);
+}
 
 typedef uint16_t bf16_t;  // raw bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -185,10 +185,11 @@ extern "C" int mafed_distill_fwd(const float* s, const float* t, const int64_t* 
     return MAFED_EWORKSPACE;
   }
   hipStream_t st = as_stream(stream);
-  if (cosine) distill_fwd_kernel<true><<<dim3(nblk), dim3(256), 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, (float*)workspace);
-  else distill_fwd_kernel<false><<<dim3(nblk), dim3(256), 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, (float*)workspace);
+  const double dbytes = 2.0 * rows * h * 4.0;  // student + teacher hidden state of one layer
+  if (cosine) launch(K_DISTILL_FWD, dbytes, distill_fwd_kernel<true>, dim3(nblk), dim3(256), 0, st, s, t, attention_mask, rows, S, P, S - P, h, (float*)workspace);
+  else launch(K_DISTILL_FWD, dbytes, distill_fwd_kernel<false>, dim3(nblk), dim3(256), 0, st, s, t, attention_mask, rows, S, P, S - P, h, (float*)workspace);
   MAFED_CHECK_LAUNCH("distill_fwd");
-  distill_finish_kernel<<<dim3(1), dim3(256), 0, st>>>((const float*)workspace, nblk, out4);
+  launch(K_SMALL, 0.0, distill_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, nblk, out4);
   MAFED_CHECK_LAUNCH("distill_fwd(finish)");
   return MAFED_OK;
 }
@@ -200,8 +201,9 @@ extern "C" int mafed_distill_bwd(const float* s, const float* t, const int64_t* 
   const int64_t rows = (int64_t)B * S;
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)cdiv(rows, 4)), block(256);
-  if (cosine) distill_bwd_kernel<true><<<grid, block, 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, coef_dev, ds, accumulate);
-  else distill_bwd_kernel<false><<<grid, block, 0, st>>>(s, t, attention_mask, rows, S, P, S - P, h, coef_dev, ds, accumulate);
+  const double dbytes = (accumulate ? 4.0 : 3.0) * rows * h * 4.0;
+  if (cosine) launch(K_DISTILL_BWD, dbytes, distill_bwd_kernel<true>, grid, block, 0, st, s, t, attention_mask, rows, S, P, S - P, h, coef_dev, ds, accumulate);
+  else launch(K_DISTILL_BWD, dbytes, distill_bwd_kernel<false>, grid, block, 0, st, s, t, attention_mask, rows, S, P, S - P, h, coef_dev, ds, accumulate);
   MAFED_CHECK_LAUNCH("distill_bwd");
   return MAFED_OK;
 }

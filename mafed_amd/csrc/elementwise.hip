@@ -116,10 +116,11 @@ extern "C" int mafed_cast(const void* src, mafed_dtype sd, void* dst, mafed_dtyp
   hipStream_t st = as_stream(stream);
   const int64_t n4 = n / 4;
   dim3 grid(grid_for(n4)), block(256);
-  if (sd == MAFED_F32 && dd == MAFED_BF16) cast_kernel<float, bf16_t><<<grid, block, 0, st>>>((const float*)src, (bf16_t*)dst, n4, n);
-  else if (sd == MAFED_BF16 && dd == MAFED_F32) cast_kernel<bf16_t, float><<<grid, block, 0, st>>>((const bf16_t*)src, (float*)dst, n4, n);
-  else if (sd == MAFED_F32 && dd == MAFED_F32) cast_kernel<float, float><<<grid, block, 0, st>>>((const float*)src, (float*)dst, n4, n);
-  else cast_kernel<bf16_t, bf16_t><<<grid, block, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n4, n);
+  const double cbytes = (double)n * ((sd == MAFED_F32 ? 4.0 : 2.0) + (dd == MAFED_F32 ? 4.0 : 2.0));
+  if (sd == MAFED_F32 && dd == MAFED_BF16) launch(K_CAST, cbytes, cast_kernel<float, bf16_t>, grid, block, 0, st, (const float*)src, (bf16_t*)dst, n4, n);
+  else if (sd == MAFED_BF16 && dd == MAFED_F32) launch(K_CAST, cbytes, cast_kernel<bf16_t, float>, grid, block, 0, st, (const bf16_t*)src, (float*)dst, n4, n);
+  else if (sd == MAFED_F32 && dd == MAFED_F32) launch(K_CAST, cbytes, cast_kernel<float, float>, grid, block, 0, st, (const float*)src, (float*)dst, n4, n);
+  else launch(K_CAST, cbytes, cast_kernel<bf16_t, bf16_t>, grid, block, 0, st, (const bf16_t*)src, (bf16_t*)dst, n4, n);
   MAFED_CHECK_LAUNCH("cast");
   return MAFED_OK;
 }
@@ -143,8 +144,9 @@ extern "C" int mafed_embed_concat_fwd(const void* image, mafed_dtype img_dtype, 
   if (rows == 0) return MAFED_OK;
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)cdiv(rows, 4)), block(256);
-  if (img_dtype == MAFED_F32) embed_concat_fwd_kernel<float><<<grid, block, 0, st>>>((const float*)image, embed_in, input_ids, B, P, T, h, V, h0);
-  else embed_concat_fwd_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)image, embed_in, input_ids, B, P, T, h, V, h0);
+  const double ebytes = (double)B * h * (P * (img_dtype == MAFED_F32 ? 4.0 : 2.0) + T * 4.0 + (P + T) * 4.0);
+  if (img_dtype == MAFED_F32) launch(K_EMBED_FWD, ebytes, embed_concat_fwd_kernel<float>, grid, block, 0, st, (const float*)image, embed_in, input_ids, B, P, T, h, V, h0);
+  else launch(K_EMBED_FWD, ebytes, embed_concat_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)image, embed_in, input_ids, B, P, T, h, V, h0);
   MAFED_CHECK_LAUNCH("embed_concat_fwd");
   return MAFED_OK;
 }
@@ -157,8 +159,9 @@ extern "C" int mafed_embed_concat_bwd(const float* dh0, const int64_t* input_ids
   if (rows == 0) return MAFED_OK;
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)cdiv(rows, 4)), block(256);
-  if (img_dtype == MAFED_F32) embed_concat_bwd_kernel<float><<<grid, block, 0, st>>>(dh0, input_ids, B, P, T, h, V, (float*)d_image, d_embed_in);
-  else embed_concat_bwd_kernel<bf16_t><<<grid, block, 0, st>>>(dh0, input_ids, B, P, T, h, V, (bf16_t*)d_image, d_embed_in);
+  const double ebytes = (double)B * h * ((P + T) * 4.0 + P * (img_dtype == MAFED_F32 ? 4.0 : 2.0) + T * 4.0);
+  if (img_dtype == MAFED_F32) launch(K_EMBED_BWD, ebytes, embed_concat_bwd_kernel<float>, grid, block, 0, st, dh0, input_ids, B, P, T, h, V, (float*)d_image, d_embed_in);
+  else launch(K_EMBED_BWD, ebytes, embed_concat_bwd_kernel<bf16_t>, grid, block, 0, st, dh0, input_ids, B, P, T, h, V, (bf16_t*)d_image, d_embed_in);
   MAFED_CHECK_LAUNCH("embed_concat_bwd");
   return MAFED_OK;
 }
@@ -173,8 +176,9 @@ extern "C" int mafed_colsum(const void* X, mafed_dtype dtype, int64_t M, int64_t
   if (M == 0) return MAFED_OK;
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)cdiv(N, CS_COLS), (unsigned)cdiv(M, CS_ROWS)), block(256);
-  if (dtype == MAFED_F32) colsum_kernel<float><<<grid, block, 0, st>>>((const float*)X, M, N, ldx, out);
-  else colsum_kernel<bf16_t><<<grid, block, 0, st>>>((const bf16_t*)X, M, N, ldx, out);
+  const double sbytes = (double)M * N * (dtype == MAFED_F32 ? 4.0 : 2.0);
+  if (dtype == MAFED_F32) launch(K_COLSUM, sbytes, colsum_kernel<float>, grid, block, 0, st, (const float*)X, M, N, ldx, out);
+  else launch(K_COLSUM, sbytes, colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)X, M, N, ldx, out);
   MAFED_CHECK_LAUNCH("colsum");
   return MAFED_OK;
 }

@@ -599,8 +599,8 @@ static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int6
     attr_set = true;
   }
   const int nsplit = (MT == 4 && NT == 4 && WM == 2 && WN == 2) ? g_gemm_nsplit : 1;
-  kfn<<<dim3((unsigned)nwg, (unsigned)nsplit), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi,
-                                                                               (int)tn | (g_gemm_group_m << 20), (int)nwg);
+  launch(K_GEMM_BF16, 2.0 * M * N * K, kfn, dim3((unsigned)nwg, (unsigned)nsplit), dim3(WM * WN * 64), LDS, st, M, N, K, (const bf16_t*)A, lda,
+         (const bf16_t*)B, ldb, (CT*)C, epi, (int)tn | (g_gemm_group_m << 20), (int)nwg);
   return MAFED_OK;
 }
 
@@ -909,8 +909,8 @@ static int launch_bf16(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     attr_set = true;
   }
-  kfn<<<dim3((unsigned)nwg), dim3(256), GEMM_LDS_BYTES, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi,
-                                                               (int)tn, (int)nwg);
+  launch(K_GEMM_BF16, 2.0 * M * N * K, kfn, dim3((unsigned)nwg), dim3(256), GEMM_LDS_BYTES, st, M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+         (CT*)C, epi, (int)tn, (int)nwg);
   return MAFED_OK;
 }
 
@@ -971,8 +971,8 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
   MAFED_CHECK_ARG(!colsum || beta == 0.f, "gemm: colsum with beta != 0 is not defined");
   if (in_dtype == MAFED_F32) {
     dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64)), block(256);
-    if (c_dtype == MAFED_F32) gemm_f32_kernel<float><<<grid, block, 0, st>>>(transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, epi);
-    else gemm_f32_kernel<bf16_t><<<grid, block, 0, st>>>(transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (bf16_t*)C, epi);
+    if (c_dtype == MAFED_F32) launch(K_GEMM_F32, 2.0 * M * N * K, gemm_f32_kernel<float>, grid, block, 0, st, transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (float*)C, epi);
+    else launch(K_GEMM_F32, 2.0 * M * N * K, gemm_f32_kernel<bf16_t>, grid, block, 0, st, transA, transB, M, N, K, (const float*)A, lda, (const float*)B, ldb, (bf16_t*)C, epi);
     MAFED_CHECK_LAUNCH("gemm(f32)");
     return colsum_after();
   }

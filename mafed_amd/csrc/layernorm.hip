@@ -264,7 +264,7 @@ extern "C" int mafed_layernorm_fwd(const float* x, int64_t rows, int h, float ep
   dim3 grid((unsigned)cdiv(rows, LN_ROWS_PER_BLOCK)), block(256);
   hipStream_t st = as_stream(stream);
 #define LAUNCH(NV, T) \
-  layernorm_fwd_kernel<NV, T><<<grid, block, 0, st>>>(x, rows, h, eps, w1, b1, (T*)y1, w2, b2, (T*)y2, mean, rstd)
+  launch(K_LN_FWD, (double)rows * h * (4.0 + (y2 ? 2.0 : 1.0) * sizeof(T)), layernorm_fwd_kernel<NV, T>, grid, block, 0, st, x, rows, h, eps, w1, b1, (T*)y1, w2, b2, (T*)y2, mean, rstd)
 #define DISPATCH_T(NV)                      \
   if (out_dtype == MAFED_F32) LAUNCH(NV, float); \
   else LAUNCH(NV, bf16_t)
@@ -316,10 +316,13 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
   do {                                                                                                                   \
     auto kfn = layernorm_bwd_kernel<NV, T, DUAL, DXS>;                                                                        \
     if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-    kfn<<<grid, block, lds_bytes, st>>>((const T*)dy1, (const T*)dy2, x, mean, rstd, w1, w2, rows, h, dres, dx, (T*)dx_lp, \
-                                        teacher, attention_mask, S, P, T_, inj_scale_dev, inj_mul, partial);                      \
+    launch(K_LN_BWD, ln_bwd_bytes, kfn, grid, block, lds_bytes, st, (const T*)dy1, (const T*)dy2, x, mean, rstd, w1, w2, rows, h, dres, dx, (T*)dx_lp, \
+           teacher, attention_mask, S, P, T_, inj_scale_dev, inj_mul, partial);                                               \
   } while (0)
   const int T_ = T;
+  // algorithmic bytes: dy1 (+ dy2) and x in, the residual gradient and the teacher rows where present, dx (+ its low-precision copy) out
+  const double esz = dy_dtype == MAFED_F32 ? 4.0 : 2.0;
+  const double ln_bwd_bytes = (double)rows * h * ((dual ? 2.0 : 1.0) * esz + 4.0 + (dres ? 4.0 : 0.0) + (teacher ? 4.0 : 0.0) + 4.0 + (dx_lp ? esz : 0.0));
 #define DISPATCH_D(NV, TT)                       \
   if (dual && dxsum) LAUNCH(NV, TT, true, true);  \
   else if (dual) LAUNCH(NV, TT, true, false);     \
@@ -340,8 +343,8 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
 #undef LAUNCH
   MAFED_CHECK_LAUNCH("layernorm_bwd");
   const int tot = np * h;
-  ln_param_reduce_kernel<<<dim3((tot + 63) / 64), dim3(256), 0, st>>>(partial, nblk, np, h, dw1, db1, dw2, db2, dxsum ? np - 1 : -1,
-                                                                      dxsum_a, dxsum_b);
+  launch(K_LN_BWD_REDUCE, (double)nblk * np * h * 4.0, ln_param_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, partial, nblk, np, h, dw1,
+         db1, dw2, db2, dxsum ? np - 1 : -1, dxsum_a, dxsum_b);
   MAFED_CHECK_LAUNCH("layernorm_bwd(param reduce)");
   return MAFED_OK;
 }

@@ -134,9 +134,9 @@ extern "C" int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, fl
   int64_t nb = cdiv(n / 4 + 1, 256 * 4);
   if (nb > GN_BLOCKS) nb = GN_BLOCKS;
   if (nb < 1) nb = 1;
-  gradnorm_partial_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(g, n, (float*)workspace);
+  launch(K_GRADNORM, (double)n * 4.0, gradnorm_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, g, n, (float*)workspace);
   MAFED_CHECK_LAUNCH("gradnorm(partial)");
-  gradnorm_finish_kernel<<<dim3(1), dim3(256), 0, st>>>((const float*)workspace, (int)nb, max_norm, out2);
+  launch(K_SMALL, 0.0, gradnorm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)nb, max_norm, out2);
   MAFED_CHECK_LAUNCH("gradnorm(finish)");
   return MAFED_OK;
 }
@@ -155,12 +155,13 @@ extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, in
   hipStream_t st = as_stream(stream);
   int64_t nb = cdiv(n / 4 + 1, 256);
   if (nb > 4096) nb = 4096;
+  // algorithmic bytes: p, m, v read + written, g read (+ the bf16 shadow weight written) = 28 (30) bytes per parameter
   if (p_bf16)
-    adamw_kernel<true><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, (float)bc1,
-                                                                 (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16);
+    launch(K_ADAMW, (double)n * 30.0, adamw_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay,
+           (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16);
   else
-    adamw_kernel<false><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, (float)bc1,
-                                                                  (float)sqrt(bc2), clip_dev, grad_mul, nullptr);
+    launch(K_ADAMW, (double)n * 28.0, adamw_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay,
+           (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)nullptr);
   MAFED_CHECK_LAUNCH("adamw_step");
   return MAFED_OK;
 }

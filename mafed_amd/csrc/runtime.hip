@@ -13,5 +13,73 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace mafed
 
-extern "C" int mafed_version(void) { return 100; }
+// ---- kernel profiler -------------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+
+namespace mafed {
+bool g_prof_on = false;
+namespace {
+struct ProfRec { int tag; double work; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;                 // launches come from the caller's thread AND from autograd's backward thread
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;  // events are created once per process and re-used by later profiles
+size_t g_prof_cap = 0;
+const char* const kTagNames[K_TAG_COUNT] = {
+    "gemm_bf16", "gemm_f32", "gemm_skinny", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_exact", "layernorm_fwd", "layernorm_bwd",
+    "layernorm_bwd_reduce", "ce_fwd", "ce_bwd", "distill_fwd", "distill_bwd", "adamw", "gradnorm", "embed_concat_fwd", "embed_concat_bwd",
+    "colsum", "cast", "ewc", "small"};
+}  // namespace
+
+bool prof_events(int tag, double work, hipEvent_t* e0, hipEvent_t* e1) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on || g_prof_recs.size() >= g_prof_cap) return false;  // a full profile degrades to plain launches
+  const size_t i = g_prof_recs.size();
+  *e0 = g_prof_pool[2 * i];
+  *e1 = g_prof_pool[2 * i + 1];
+  g_prof_recs.push_back(ProfRec{tag, work, *e0, *e1});
+  return true;
+}
+}  // namespace mafed
+
+extern "C" int mafed_prof_begin(int max_records) {
+  using namespace mafed;
+  MAFED_CHECK_ARG(max_records > 0 && max_records <= (1 << 22), "prof_begin: max_records %d out of range", max_records);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  while (g_prof_pool.size() < (size_t)2 * max_records) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { set_error("prof_begin: hipEventCreate failed"); return MAFED_ELAUNCH; }
+    g_prof_pool.push_back(e);
+  }
+  g_prof_recs.clear();
+  g_prof_cap = (size_t)max_records;
+  g_prof_on = true;
+  return MAFED_OK;
+}
+
+extern "C" int mafed_prof_end(void) {
+  std::lock_guard<std::mutex> lk(mafed::g_prof_mu);
+  mafed::g_prof_on = false;
+  return MAFED_OK;
+}
+
+// The caller has synchronised the device.  Fills up to `max` records in launch order and returns how many a profile holds.
+extern "C" int mafed_prof_collect(int* tags, double* work, float* ms, int max) {
+  using namespace mafed;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const int n = (int)g_prof_recs.size();
+  for (int i = 0; i < n && i < max; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof_recs[i].e0, g_prof_recs[i].e1) != hipSuccess) t = -1.f;
+    if (tags) tags[i] = g_prof_recs[i].tag;
+    if (work) work[i] = g_prof_recs[i].work;
+    if (ms) ms[i] = t;
+  }
+  (void)hipGetLastError();
+  return n;
+}
+
+extern "C" const char* mafed_prof_tag_name(int tag) { return (tag >= 0 && tag < mafed::K_TAG_COUNT) ? mafed::kTagNames[tag] : "?"; }
+
+extern "C" int mafed_version(void) { return 110; }
 extern "C" const char* mafed_last_error_string(void) { return mafed::g_err; }

@@ -4,8 +4,9 @@ One process per GPU; replicas hold the full student, teacher and optimiser state
 data-path collective is the gradient mean, once per optimiser step: the flat fp32 gradient buffer is cut into
 contiguous buckets that follow the order in which the hand-scheduled backward finishes them (LM head first, then
 layers L-1 .. 0, then embeddings / projector / all biases); each bucket is all-reduced over RCCL on a side HIP stream
-as soon as its last layer is done, overlapping the rest of backward.  Gradients are identical on every rank afterwards,
-so the global-norm clip needs no further collective.  Teacher weights are broadcast once per task.
+as soon as its last layer is done, overlapping the rest of backward -- as one all-reduce, or as reduce-scatter + all-gather
+(all seven xGMI links of a GPU busy at once), in fp32 or through bf16 staging buffers.  Gradients are identical on every
+rank afterwards, so the global-norm clip needs no further collective.  Teacher weights are broadcast once per task.
 """
 from __future__ import annotations
 
@@ -37,14 +38,32 @@ def layer_ranges(model) -> Tuple[List[Tuple[int, int]], Tuple[int, int], List[Tu
 
 
 class GradReducer:
-    """Bucketed, backward-overlapped all-reduce(mean) of ``flat_grads``.  Works on any object exposing
-    ``flat_grads``, ``grad_ready_hook``, ``_offsets``, ``config.num_hidden_layers`` and ``decay_split()`` (the CPU/gloo
-    tests drive it with a stand-in), so the bucket logic is testable without a GPU."""
+    """Bucketed, backward-overlapped gradient mean over ``flat_grads``.  Works on any object exposing ``flat_grads``,
+    ``grad_ready_hook``, ``_offsets``, ``config.num_hidden_layers`` and ``decay_split()`` (the CPU/gloo tests drive it with a
+    stand-in), so the bucket logic is testable without a GPU.
 
-    def __init__(self, model, process_group=None, bucket_mb: float = 64.0):
+    ``mode``        "all_reduce": one ``all_reduce`` per bucket.
+                    "reduce_scatter": ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` per bucket -- on the MI355X
+                    node's point-to-point xGMI mesh (7 links x ~153 GB/s per GPU) a direct exchange keeps all seven links busy
+                    (1/8 of the bucket per peer per phase), where a single ring is bound by one link per hop (SURVEY.md section 5:
+                    ~2.7 ms vs ~18.6 ms for the 1.63 GB of fp32 gradients at 410M).
+    ``grad_dtype``  None: buckets travel as fp32.  torch.bfloat16: each bucket is cast into a bf16 staging buffer, reduced in
+                    bf16 and cast back (half the bytes on the links; the sum of <= 8 bf16 values per element).
+    ``average``     "auto": ``ReduceOp.AVG`` on RCCL, ``SUM`` followed by a division elsewhere; True / False force one form
+                    (both are covered by tests/test_dist_gloo.py: gloo implements AVG too)."""
+
+    def __init__(self, model, process_group=None, bucket_mb: float = 64.0, grad_dtype: Optional[torch.dtype] = None,
+                 mode: str = "all_reduce", average="auto"):
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"unknown reduce mode {mode!r}")
+        if grad_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError(f"unsupported gradient bucket dtype {grad_dtype}")
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.mode = mode
+        self.grad_dtype = torch.bfloat16 if grad_dtype == torch.bfloat16 else None
         self.enabled = True
         per_layer, head, tail = layer_ranges(model)
         L = len(per_layer)
@@ -65,15 +84,64 @@ class GradReducer:
         self._by_trigger = {}
         for trig, rng in self.buckets:
             self._by_trigger.setdefault(trig, []).append(rng)
+        if mode == "reduce_scatter":
+            for _, (lo, hi) in self.buckets:  # every tensor starts on a 64-element boundary, so 2 / 4 / 8 ranks divide a bucket
+                if (hi - lo) % max(1, self.world):
+                    raise ValueError(f"bucket [{lo}, {hi}) is not divisible by the world size {self.world}")
         self._works = []
+        self._staging = {}  # (lo, hi) -> bf16 staging buffer / fp32 shard buffer, allocated once
         self._use_cuda = model.flat_grads.is_cuda
         self._side = torch.cuda.Stream(device=model.flat_grads.device) if self._use_cuda else None
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
-        self._avg = backend == "nccl"
+        self._nccl = backend == "nccl"
+        self._avg = self._nccl if average == "auto" else bool(average)
+        self.bytes_per_step = 0  # payload handed to the collectives in the last window (diagnostics / bench line)
         model.grad_ready_hook = self._on_ready
 
     def covered(self) -> int:
         return sum(hi - lo for _, (lo, hi) in self.buckets)
+
+    def _buf(self, key, n, dtype, device):
+        b = self._staging.get(key)
+        if b is None:
+            b = self._staging[key] = torch.empty(n, dtype=dtype, device=device)
+        return b
+
+    def _cast(self, src, dst):
+        if src.is_cuda:
+            from mafed_amd import ops
+            ops.cast(src, dst.dtype, out=dst)
+        else:
+            dst.copy_(src)
+
+    def _reduce_bucket(self, lo: int, hi: int):
+        """Issue the collective(s) of one bucket; returns (works, finish) where finish() runs once they are complete."""
+        g32 = self.model.flat_grads[lo:hi]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if self.grad_dtype is not None:
+            buf = self._buf(("lp", lo, hi), hi - lo, self.grad_dtype, g32.device)
+            self._cast(g32, buf)
+        else:
+            buf = g32
+        self.bytes_per_step += buf.numel() * buf.element_size()
+        works = []
+        if self.mode == "all_reduce":
+            works.append(dist.all_reduce(buf, op=op, group=self.pg, async_op=True))
+        else:
+            n = (hi - lo) // self.world
+            shard = self._buf(("shard", lo, hi), n, buf.dtype, buf.device)
+            w = dist.reduce_scatter_tensor(shard, buf, op=op, group=self.pg, async_op=True)
+            if not self._nccl:
+                w.wait()  # RCCL runs a group's collectives in issue order on its own stream; gloo's worker threads do not
+            works.append(w)
+            works.append(dist.all_gather_into_tensor(buf, shard, group=self.pg, async_op=True))
+
+        def finish():
+            if self.grad_dtype is not None:
+                self._cast(buf, g32)
+            if not self._avg:
+                g32.div_(self.world)
+        return works, finish
 
     def _on_ready(self, trigger: int) -> None:
         if not self.enabled or self.world == 1:
@@ -81,24 +149,31 @@ class GradReducer:
         for lo, hi in self._by_trigger.get(trigger, ()):
             if hi <= lo:
                 continue
-            buf = self.model.flat_grads[lo:hi]
             if self._use_cuda:
                 self._side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._side):
-                    w = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    self._works.append(self._reduce_bucket(lo, hi))
             else:
-                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append((w, buf))
+                self._works.append(self._reduce_bucket(lo, hi))
 
     def wait(self) -> None:
-        """Call before clipping / the optimiser step: the compute stream waits for every bucket."""
-        for w, buf in self._works:
-            w.wait()
-            if not self._avg:
-                buf.div_(self.world)
+        """Call before clipping / the optimiser step: the compute stream waits for every bucket (and its cast back)."""
         if self._use_cuda and self._works:
+            with torch.cuda.stream(self._side):
+                for works, finish in self._works:
+                    for w in works:
+                        w.wait()
+                    finish()
             torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            for works, finish in self._works:
+                for w in works:
+                    w.wait()
+                finish()
         self._works = []
+
+    def begin_window(self) -> None:
+        self.bytes_per_step = 0
 
 
 def broadcast_teacher(model, src: int = 0, process_group=None) -> None:

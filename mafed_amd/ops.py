@@ -69,11 +69,6 @@ def workspace(device) -> Workspace:
     return ws
 
 
-# bench.py's live roofline measurement: when a list is installed here every bf16 MFMA GEMM launch is bracketed by HIP
-# events on the launch stream and (start, end, flops) is appended (mafed_amd.ops.GEMM_EVENTS = []).
-GEMM_EVENTS = None
-
-
 def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Optional[torch.Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
          aux: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
@@ -91,10 +86,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
     assert out.shape == (M, N) and out.stride(1) == 1
     if res1 is not None and res1.dtype == torch.bfloat16:
         epilogue |= EPI_RES1_BF16
-    prof = GEMM_EVENTS is not None and A.dtype == torch.bfloat16
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     if colsum is None:
         rc = _fn.gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
                       out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream())
@@ -105,9 +96,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
                              _ptr(colsum), _stream())
     if rc:
         check(rc, "mafed_gemm")
-    if prof:
-        e1.record()
-        GEMM_EVENTS.append((e0, e1, 2.0 * M * N * K))
     return out
 
 

@@ -20,50 +20,10 @@ from mafed_amd.dist import GradReducer
 from mafed_amd.optim import FlatAdamW, compute_warmup, get_linear_schedule_with_warmup
 
 
-class _StaticLoader:
-    """``next(iter(loader))`` yields (a shallow copy of) one static batch dict: the buffers a captured graph reads."""
-
-    def __init__(self, static_batch: Dict[str, torch.Tensor]):
-        self.static = static_batch
-
-    def __iter__(self):
-        while True:
-            yield dict(self.static)
-
-
-class _GraphedStep:
-    """One variant (replay / task branch x with / without optimiser step) of the device part of a step, captured into a
-    hipGraph: forward, loss, hand-scheduled backward on two streams, clip, AdamW, gradient zeroing.  Replaying it costs
-    one launch; the ~1700 kernel launches of an eager step cost more host time than the GPU needs to run them."""
-
-    def __init__(self, trainer: "Trainer", is_replay: bool, window_end: bool, task_batch, mem_batch):
-        self.static_task = {k: v.clone() for k, v in task_batch.items() if isinstance(v, torch.Tensor)}
-        self.static_mem = {k: v.clone() for k, v in mem_batch.items() if isinstance(v, torch.Tensor)} if mem_batch is not None else None
-        self.graph = torch.cuda.CUDAGraph()
-        real_loader = trainer.cl_method.mem_dataloader if is_replay else None
-        if is_replay:
-            trainer.cl_method.mem_dataloader = _StaticLoader(self.static_mem)
-        try:
-            with torch.cuda.graph(self.graph):
-                self.rec = trainer._device_step(self.static_task, is_replay, window_end)
-        finally:
-            if is_replay:
-                trainer.cl_method.mem_dataloader = real_loader
-
-    def replay(self, task_batch, mem_batch):
-        for k, v in self.static_task.items():
-            v.copy_(task_batch[k], non_blocking=True)
-        if self.static_mem is not None:
-            for k, v in self.static_mem.items():
-                v.copy_(mem_batch[k], non_blocking=True)
-        self.graph.replay()
-        return self.rec
-
-
 class Trainer:
     def __init__(self, model, cl_method, config: Optional[Any] = None, task_id: int = 0, n_batches_per_epoch: int = 1000,
-                 process_group=None, ddp: bool = False, bucket_mb: float = 64.0, use_graphs: bool = False,
-                 pipeline_optimizer: bool = False):
+                 process_group=None, ddp: bool = False, bucket_mb: float = 64.0, pipeline_optimizer: bool = False,
+                 grad_dtype: Optional[torch.dtype] = None, reduce_mode: str = "all_reduce"):
         cfg = config if config is not None else SimpleNamespace()
         self.config = cfg
         self.model = model
@@ -81,17 +41,12 @@ class Trainer:
                                      getattr(cfg, "warmup_steps", None))
         total = int(getattr(cfg, "total_steps", total))
         self.scheduler = get_linear_schedule_with_warmup(self.optimizer, warm, total, last_epoch=-1)
-        self.reducer = GradReducer(model, process_group, bucket_mb) if ddp else None
-        # hipGraph replay of the device part of a step.  Needs fixed batch shapes and CL hooks that do no per-step host work
-        # (true for Naive / ER / FeatureDistillation, whose update_after_* are no-ops on this path).
-        self.use_graphs = bool(use_graphs) and self.reducer is None
+        self.reducer = GradReducer(model, process_group, bucket_mb, grad_dtype=grad_dtype, mode=reduce_mode) if ddp else None
         # AdamW + gradient zeroing chunk by chunk on their own stream, the next forward waiting per layer (FlatAdamW.
         # apply_pipelined).  Opt-in: between step() calls the caller's stream may then only reach the parameters through the
         # model's forward, or after join().
-        self.pipeline_optimizer = bool(pipeline_optimizer) and not self.use_graphs and torch.cuda.is_available()
+        self.pipeline_optimizer = bool(pipeline_optimizer) and torch.cuda.is_available()
         self._opt_stream = torch.cuda.Stream(device=model.flat_params.device) if self.pipeline_optimizer else None
-        self._graphs: Dict[Any, _GraphedStep] = {}
-        self._eager_seen: Dict[Any, int] = {}
         self.global_step = 0
         self.optimizer.zero_grad()
         self.on_train_start()
@@ -121,9 +76,13 @@ class Trainer:
         return loss, branch
 
     def _device_step(self, batch, is_replay: bool, window_end: bool) -> Dict[str, Any]:
-        """Everything of a step that runs on the GPU, in Lightning's order (capturable: no host synchronisation)."""
+        """Everything of a step that runs on the GPU, in Lightning's order (no host synchronisation).  Launches are eager: a
+        hipGraph replay of this sequence measured slower than multi-stream eager launches on ROCm 7 (42.9 vs 39.7 ms at 410M),
+        so the capture path of round 1 was removed rather than kept untested."""
         if self.reducer is not None:
-            self.reducer.enabled = window_end  # all-reduce only on the last micro-batch of an accumulation window
+            self.reducer.enabled = window_end  # the gradient mean runs only on the last micro-batch of an accumulation window
+            if window_end:
+                self.reducer.begin_window()
         loss, branch = self._training_step(batch, is_replay)
         (loss / self.accumulate if self.accumulate != 1 else loss).backward()
         if torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
@@ -155,19 +114,8 @@ class Trainer:
     def step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, Any]:
         window_end = (batch_idx + 1) % self.accumulate == 0
         is_replay = self._is_replay_step(batch_idx) and getattr(self.cl_method, "mem_dataloader", True) is not None
-        key = (is_replay, window_end)
         lr_now = self.optimizer.param_groups[0]["lr"]
-        if self.use_graphs and (key in self._graphs or self._eager_seen.get(key, 0) >= 2):
-            mem = next(iter(self.cl_method.mem_dataloader)) if is_replay else None
-            gs = self._graphs.get(key)
-            if gs is None:
-                torch.cuda.synchronize()
-                gs = self._graphs[key] = _GraphedStep(self, is_replay, window_end, batch, mem)
-                rec = dict(gs.rec)  # the capture pass itself does not execute: replay it once for this step
-            rec = dict(gs.replay(batch, mem))
-        else:
-            rec = self._device_step(batch, is_replay, window_end)
-            self._eager_seen[key] = self._eager_seen.get(key, 0) + 1
+        rec = self._device_step(batch, is_replay, window_end)
         if window_end:
             rec["lr"] = lr_now
             self.optimizer.host_advance()

@@ -1,6 +1,6 @@
-"""GPU, two ranks sharing the box's one GPU over gloo (RCCL refuses two ranks on one device): the data-parallel step --
-hand-scheduled backward on two streams, bucket hooks, side-stream all-reduce, clip, AdamW -- must equal a single
-process that averages the two ranks' gradients itself."""
+"""GPU, two or four ranks sharing the box's one GPU over gloo (RCCL refuses two ranks on one device): the data-parallel step --
+hand-scheduled backward on two streams, bucket hooks, side-stream gradient mean (all-reduce, or reduce-scatter + all-gather,
+fp32 or bf16 buckets), clip, AdamW -- must equal a single process that averages the ranks' gradients itself."""
 import os
 import socket
 import types
@@ -34,7 +34,7 @@ def _build(cfg, sd, dtype=torch.float32):
     return m
 
 
-def _make(cfg, sd, tsd, ddp, rank_batches, pipeline=False):
+def _make(cfg, sd, tsd, ddp, rank_batches, pipeline=False, mode="all_reduce", grad_dtype=None):
     from mafed_amd import FeatureDistillation, Trainer
     t = TINY["m64"]
     model, teacher = _build(cfg, sd), _build(cfg, tsd)
@@ -47,7 +47,7 @@ def _make(cfg, sd, tsd, ddp, rank_batches, pipeline=False):
     fd.num_vision_tokens = cfg.num_vision_tokens
     conf = types.SimpleNamespace(accumulate_grad_batches=2, replay_interval=2, grad_norm=2.0, learning_rate=1e-3, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_steps=1, total_steps=10)
-    tr = Trainer(model, fd, conf, task_id=1, ddp=ddp, bucket_mb=0.05, pipeline_optimizer=pipeline)
+    tr = Trainer(model, fd, conf, task_id=1, ddp=ddp, bucket_mb=0.05, pipeline_optimizer=pipeline, reduce_mode=mode, grad_dtype=grad_dtype)
     return model, fd, tr
 
 
@@ -56,7 +56,7 @@ def _batches(cfg, rank):
     return [{k: v.cuda() for k, v in R.make_batch(cfg, t["B"], t["T"], seed=100 + 10 * rank + i, pad=True, n_answer=3).items()} for i in range(4)]
 
 
-def _worker(rank, world, port, q, pipeline=False):
+def _worker(rank, world, port, q, pipeline=False, mode="all_reduce", grad_dtype=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
@@ -65,7 +65,8 @@ def _worker(rank, world, port, q, pipeline=False):
         cfg = tiny_cfg("m64")
         sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
         tsd = R.perturb(sd, seed=22, std=5e-3)
-        model, fd, tr = _make(cfg, sd, tsd, True, None, pipeline=pipeline)
+        model, fd, tr = _make(cfg, sd, tsd, True, None, pipeline=pipeline, mode=mode, grad_dtype=grad_dtype)
+        assert tr.reducer.world == world and tr.reducer.mode == mode
         bs = _batches(cfg, rank)
         gns = []
         for i in range(4):  # accumulate 2, replay every 2nd micro-batch: two optimiser steps
@@ -80,34 +81,38 @@ def _worker(rank, world, port, q, pipeline=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("pipeline", [False, True])
-def test_ddp_step_equals_mean_of_rank_gradients(pipeline):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,pipeline,mode,grad_dtype", [
+    (2, False, "all_reduce", None), (2, True, "all_reduce", None),
+    (2, True, "reduce_scatter", None), (2, True, "reduce_scatter", torch.bfloat16),
+    (4, True, "all_reduce", None), (4, True, "reduce_scatter", torch.bfloat16)])
+def test_ddp_step_equals_mean_of_rank_gradients(world, pipeline, mode, grad_dtype):
     """pipeline=True: the ranks run Trainer(pipeline_optimizer=True) (AdamW chunks on their own stream behind the bucket
-    all-reduces, next forward waiting per layer) -- what bench.py launches at N > 1."""
-    world = 2
+    collectives, next forward waiting per layer) -- what bench.py launches at N > 1."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, pipeline)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, pipeline, mode, grad_dtype)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    res = sorted([q.get(timeout=400) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(30)
+    assert len(res) == world
     # replicas stay identical
-    assert np.array_equal(res[0][2], res[1][2])
-    assert res[0][1] == res[1][1]
-    # single-process emulation: run both ranks' micro-batches, average gradients by hand before the optimiser step
+    for r in range(1, world):
+        assert np.array_equal(res[0][2], res[r][2])
+        assert res[0][1] == res[r][1]
+    # single-process emulation: run every rank's micro-batches, average gradients by hand before the optimiser step
     cfg = tiny_cfg("m64")
     sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
     tsd = R.perturb(sd, seed=22, std=5e-3)
     model, fd, tr = _make(cfg, sd, tsd, False, None)
-    bs = [_batches(cfg, 0), _batches(cfg, 1)]
+    bs = [_batches(cfg, r) for r in range(world)]
     gns = []
     for step in range(2):
         acc = torch.zeros_like(model.flat_grads)
-        for rank in range(2):
+        for rank in range(world):
             model.flat_grads.zero_()
             for j in range(2):
                 i = 2 * step + j
@@ -115,11 +120,15 @@ def test_ddp_step_equals_mean_of_rank_gradients(pipeline):
                 loss, _ = tr.training_step(dict(bs[rank][i]), i)
                 (loss / 2).backward()
             acc += model.flat_grads
-        model.flat_grads.copy_(acc / 2)
+        model.flat_grads.copy_(acc / world)
         gns.append(float(tr.optimizer.clip_grad_norm_(2.0)))
         tr.optimizer.step()
         tr.scheduler.step()
         tr.optimizer.zero_grad()
     torch.cuda.synchronize()
-    np.testing.assert_allclose(res[0][1], gns, rtol=1e-5)
-    np.testing.assert_allclose(res[0][2], model.flat_params.detach().cpu().numpy(), rtol=0, atol=2e-6)
+    if grad_dtype is None:
+        np.testing.assert_allclose(res[0][1], gns, rtol=1e-5)
+        np.testing.assert_allclose(res[0][2], model.flat_params.detach().cpu().numpy(), rtol=0, atol=2e-6)
+    else:  # bf16 buckets: every gradient element carries a 2^-9 relative rounding; AdamW's normalised update keeps it bounded by lr
+        np.testing.assert_allclose(res[0][1], gns, rtol=1e-2)
+        np.testing.assert_allclose(res[0][2], model.flat_params.detach().cpu().numpy(), rtol=0, atol=2.5e-3)

@@ -120,7 +120,7 @@ def test_ewc_step_with_reference_fisher_and_trainer_hook_order():
     close(total, float(g["step/total"]), 2e-2, "ce + penalty (reference Fisher)")
     conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=4, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_perc=0.1)
-    tr = Trainer(model, ewc, conf, task_id=1, n_batches_per_epoch=10, ddp=False, use_graphs=False)
+    tr = Trainer(model, ewc, conf, task_id=1, n_batches_per_epoch=10, ddp=False)
     before = model.flat_params.clone()
     rec = tr.step(to_dev(batch), 0)
     assert rec["branch"] == "task" and rec["stepped"]

@@ -56,15 +56,25 @@ def _int_mat(shape, g, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27])
+GEMM_SHAPES = [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320), (288, 512, 192),
+               (576, 384, 128), (576, 768, 256), (384, 256, 128)]
+# variants on the product path: 0 automatic dispatch, 1 register-staged kernel (ragged shapes), 21 / 27 the 144x128 and 192x128
+# LDS-DMA tiles the dispatcher picks for M = 9216 -- the full shape x transpose matrix.  The measured-and-kept-for-reference tile
+# configurations behind mafed_gemm_set_variant get ONE qualifying shape each (all four transpose modes).
+GEMM_CASES = [(v, s) for v in (0, 1, 21, 27) for s in GEMM_SHAPES] + [
+    (11, (512, 768, 320)), (12, (512, 768, 320)), (13, (384, 640, 192)), (14, (512, 768, 320)), (15, (512, 768, 320)), (16, (384, 640, 192)),
+    (17, (384, 640, 192)), (18, (512, 768, 320)), (22, (576, 384, 128)), (23, (576, 768, 256)), (24, (384, 640, 192)), (25, (384, 640, 192)),
+    (26, (576, 768, 256))]
+
+
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024, 256, 512), (384, 640, 192), (512, 768, 320), (288, 512, 192), (576, 384, 128), (576, 768, 256), (384, 256, 128)])
-def test_gemm_bf16_exact_integers(tA, tB, M, N, K, variant):
+@pytest.mark.parametrize("variant,shape", GEMM_CASES)
+def test_gemm_bf16_exact_integers(tA, tB, shape, variant):
     """Small-integer operands are exact in bf16 and the fp32 accumulator: any wrong fragment / transposing-read /
     swizzle mapping shows up as a hard mismatch (asymmetric data)."""
     ops = _ops()
     g = torch.Generator().manual_seed(7)
-    Mm, Kk = (M, K)
+    M, N, K = shape
     if tA and M % 8:
         pytest.skip("contiguous extent must be a multiple of 8")
     if not tA and K % 8:
@@ -335,7 +345,9 @@ def test_attention_f32(B, P, T, H, D):
 
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("B,P,T,H,D", [(2, 8, 6, 2, 64), (2, 40, 24, 2, 128), (3, 70, 13, 2, 64), (2, 256, 32, 4, 64), (1, 200, 57, 2, 128),
-                                       (1, 600, 41, 1, 64), (2, 129, 1, 2, 64)])
+                                       (1, 600, 41, 1, 64), (2, 129, 1, 2, 64),
+                                       # head_dim 256 (VLPythia-1B, mafed/utils/download_models.py:6-24): K / V tiled through LDS
+                                       (1, 8, 6, 1, 256), (2, 256, 32, 2, 256), (2, 70, 13, 1, 256)])
 def test_attention_bf16_mfma(B, P, T, H, D, variant):
     """variant 0: one-block-per-head resident kernels where K/V fit in LDS (S <= 640 at D = 64), else tiled; 1: tiled only."""
     ops = _ops()

@@ -224,7 +224,7 @@ def test_adaptive_weights_pass_vs_reference_golden():
         close(imp, g["g7/lang_importances"], TOL, "adaptive lang importances")
 
 
-@pytest.mark.parametrize("name", ["t64", "m64", "t128"])
+@pytest.mark.parametrize("name", ["t64", "m64", "t128", "t256"])
 def test_bf16_mode_tracks_oracle_autocast(name):
     """Perf-path numerics (bf16 MFMA GEMMs/attention, fp32 residual stream) against the oracle run under bf16
     autocast -- what the reference's Lightning precision="bf16" computes.  Loose tolerance: both sides round to bf16."""
