@@ -38,6 +38,7 @@ enum {
   MAFED_EPI_NONE = 0,
   MAFED_EPI_GELU = 1,     /* C = gelu_erf(acc + bias); aux (if non-NULL) receives the pre-activation acc + bias */
   MAFED_EPI_GELU_BWD = 2, /* C = (acc) * gelu_erf'(aux) ; aux = saved pre-activation, same dtype as C */
+  MAFED_EPI_QUICK_GELU = 3, /* C = x * sigmoid(1.702 x), x = acc + bias: MLP activation of the frozen CLIP vision tower (clip:338-350) */
   MAFED_EPI_RES1_BF16 = 0x100 /* flag, OR-ed in: res1 points at bf16 data (the attention branch output under bf16 autocast) */
 };
 
@@ -184,6 +185,16 @@ int mafed_distill_fwd(const float* s, const float* t, const int64_t* attention_m
 int mafed_distill_bwd(const float* s, const float* t, const int64_t* attention_mask, int B, int S, int P, int h,
                       int cosine, const float* coef_dev, float* ds, int accumulate, void* stream);
 /* CLS variant (:251-257): token 0 only, cosine, mean over batch -> out[1]; bwd with coef_dev[1] = upstream/B */
+/* The scalar tail of distill() for every distilled layer in one launch (mafed/methods/distillation.py:105-122,147-162;
+ * distillation_loss_weights.py:71-79): from sums[n_layers][4] = {sum_lang, sum_vis, n_lang, n_vis} (mafed_distill_fwd) and the device
+ * vector layer_coeff[n_layers] (layer coefficient x distillation_coeff) it writes per_layer[l] = lw * sum_lang / n_lang + vw * sum_vis / n_vis,
+ * modality[l] = {lang mean, vision mean}, loss = sum_l coeff[l] * per_layer[l], and inject[l] = d loss / d {sum_lang, sum_vis, ., .}
+ * (the coefficients mafed_layernorm_bwd's fused injection takes, to be scaled by the upstream gradient of the loss).
+ * modality_mode 0 "equal": lw = n_lang / (n_lang + n_vis); 1 "balanced": lw = lang_weight; 2 "adaptive": lw = lang_weight_vec[l]. */
+int mafed_distill_combine(const float* sums, int n_layers, const float* layer_coeff_dev, int modality_mode, float lang_weight,
+                          const float* lang_weight_vec_dev, float* loss_out, float* per_layer_out, float* modality_out,
+                          float* inject_out, void* stream);
+
 int mafed_distill_cls_fwd(const float* s, const float* t, int B, int S, int h, float* out1, void* stream);
 int mafed_distill_cls_bwd(const float* s, const float* t, int B, int S, int h, const float* coef_dev, float* ds,
                           int accumulate, void* stream);
@@ -205,6 +216,11 @@ int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, co
                      float eps, float weight_decay, int step, const float* clip_dev /* out2 of gradnorm or NULL */,
                      float grad_mul, void* p_bf16, void* stream);
 
+/* mafed_adamw_step that also writes zeros over g in the same pass (optimizer.zero_grad() of the next accumulation window). */
+int mafed_adamw_step_zero_grad(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                               float eps, float weight_decay, int step, const float* clip_scale_dev, float grad_mul, void* p_bf16,
+                               void* stream);
+
 /* Device-resident schedule (mafed/optim/sched.py:34-48 + the bias corrections of adamw.py:94-97): state_dev[0] = number of
  * optimiser steps taken so far; increments it to t and writes hyper3_dev = {base_lr * lambda(t-1), 1-b1^t, sqrt(1-b2^t)}
  * (double precision inside) for mafed_adamw_step(step = 0).  total_steps <= 0 means a constant learning rate. */
@@ -215,6 +231,21 @@ int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps
 int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype dst_dtype, int64_t n, void* stream);
 /* y = gelu_erf(x) elementwise (used by tests; the product path fuses GELU into mafed_gemm) */
 int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream);
+
+/* ---- frozen CLIP vision tower (mafed/model/vl_pythia.py:196-198, 453-475; clip: = transformers/models/clip/modeling_clip.py) ----
+ * The tower is ``CLIPVisionModel`` called with output_hidden_states and cut at hidden_states[-2]; its Linear layers go through
+ * mafed_gemm (fc1 with MAFED_EPI_QUICK_GELU), its LayerNorms through mafed_layernorm_fwd; the three entry points below are the rest.
+ * mafed_patchify: im2col of the stride = kernel patch convolution (clip:148-154, 209-210): pixels [B,C,H,W] ->
+ *   out [rows_out, k_pad], out[b * np + p][c * patch^2 + i * patch + j] = pixels[b][c][py * patch + i][px * patch + j]; columns
+ *   >= C * patch^2 and rows >= B * np are zero (k_pad a multiple of 64 and rows_out a multiple of the GEMM tile keep the product
+ *   on the LDS-DMA GEMM).  The patch embedding is then mafed_gemm(out, W[h, k_pad]^T).
+ * mafed_vit_assemble: tokens[b][0] = class_embedding + pos[0], tokens[b][1 + p] = patch_emb[b * np + p] + pos[1 + p] (clip:212-217), fp32.
+ * mafed_attn_fwd_bidir: softmax(q k^T D^-0.5) v over all S keys, no mask, no rotary (clip:259-277); qkv [B,S,H,3,D] as in mafed_attn_fwd. */
+int mafed_patchify(const void* pixels, mafed_dtype pix_dtype, int B, int C, int H, int W, int patch, int64_t rows_out, int k_pad,
+                   void* out, mafed_dtype out_dtype, void* stream);
+int mafed_vit_assemble(const void* patch_emb, mafed_dtype pe_dtype, int64_t ld_pe, const float* class_embedding,
+                       const float* position_embedding, int B, int num_patches, int h, float* tokens, void* stream);
+int mafed_attn_fwd_bidir(const void* qkv, mafed_dtype dtype, int B, int S, int H, int D, void* out, float* lse, void* stream);
 
 /* ---- measurement: per-kernel execution time of the launches this library makes --------------------------------------
  * No reference counterpart (the reference has no profiling); bench.py's `roofline` / `kernels` come from here.

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAFED_HIP_LIB") or os.path.join(_HERE, "libmafed_hip.so")  # override: A/B of two builds
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QUICK_GELU = 0, 1, 2, 3
 EPI_RES1_BF16 = 0x100
 
 _p, _i, _l, _f, _z, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
@@ -50,9 +50,14 @@ SIGNATURES = {
     "mafed_gradnorm_workspace_bytes": (_z, [_l]),
     "mafed_gradnorm_clip": (_i, [_p, _l, _f, _p, _p, _z, _p]),
     "mafed_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
+    "mafed_adamw_step_zero_grad": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
+    "mafed_distill_combine": (_i, [_p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p]),
     "mafed_optim_advance": (_i, [_p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_gelu": (_i, [_p, _p, _i, _l, _p]),
+    "mafed_patchify": (_i, [_p, _i, _i, _i, _i, _i, _i, _l, _i, _p, _i, _p]),
+    "mafed_vit_assemble": (_i, [_p, _i, _l, _p, _p, _i, _i, _i, _p, _p]),
+    "mafed_attn_fwd_bidir": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mafed_prof_begin": (_i, [_i]),
     "mafed_prof_end": (_i, []),
     "mafed_prof_collect": (_i, [_p, _p, _p, _i]),

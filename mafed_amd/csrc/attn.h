@@ -6,6 +6,7 @@ namespace mafed {
 
 struct AttnShape {
   int B, S, H, D, rot, T, P;
+  int causal = 1;  // 0: bidirectional (the frozen CLIP vision tower, forward only)
 };
 
 template <typename T>

@@ -36,6 +36,26 @@ extern "C" int mafed_attn_fwd(const void* qkv, mafed_dtype dtype, int B, int S, 
   return MAFED_OK;
 }
 
+// Bidirectional attention of the frozen CLIP vision tower (clip:259-277): no mask, no rotary, forward only.
+extern "C" int mafed_attn_fwd_bidir(const void* qkv, mafed_dtype dtype, int B, int S, int H, int D, void* out, float* lse, void* stream) {
+  MAFED_CHECK_ARG(qkv && out && lse, "attn_fwd_bidir: null pointer");
+  MAFED_CHECK_ARG(B > 0 && S > 0 && H > 0 && D > 0 && D <= 256, "attn_fwd_bidir: bad shape B=%d S=%d H=%d D=%d", B, S, H, D);
+  AttnShape sh{B, S, H, D, 0, 0, S};
+  sh.causal = 0;
+  const int64_t* dummy_mask = reinterpret_cast<const int64_t*>(qkv);  // never read: T = 0, every key is an "image" key
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (dtype == MAFED_F32) {
+    rc = attn_ref_fwd_launch<float>(qkv, sh, nullptr, nullptr, dummy_mask, out, lse, st);
+  } else {
+    MAFED_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "attn_fwd_bidir(bf16): qkv/out must be 16-byte aligned");
+    rc = attn_mfma_fwd_launch(qkv, sh, nullptr, nullptr, dummy_mask, out, lse, st);
+  }
+  if (rc) return rc;
+  MAFED_CHECK_LAUNCH("attn_fwd_bidir");
+  return MAFED_OK;
+}
+
 static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, mafed_dtype dtype, int B, int S, int H,
                          int D, int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* dqkv,
                          float* delta, float* dqkv_colsum, void* stream);

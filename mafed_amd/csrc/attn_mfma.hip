@@ -602,7 +602,7 @@ __device__ __forceinline__ int snake4(int w, int t) { return t * 4 + ((t & 1) ? 
 #define MAFED_LOG2E 1.4426950408889634f
 #define MAFED_LN2 0.6931471805599453f
 
-template <int D>
+template <int D, bool CAUSAL = true>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
                                                            const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse) {
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    const int last_kt = (q0 + 15) / 64;
+    const int last_kt = CAUSAL ? (q0 + 15) / 64 : (S - 1) / 64;  // bidirectional (CLIP tower): every slice sees every key tile
     // one 64-key tile; MASK = false for tiles that lie wholly below the diagonal and wholly inside the image keys (most of
     // them): no bias read, no compares.  nj = 16-key sub-tiles with a key <= q0 + 15.
     auto tile = [&](const int kt, const int nj, auto mask_tag) {
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
             for (int r = 0; r < 4; ++r) {
               const int key = kt * 64 + j * 16 + 4 * g + r;
               float v = s[j][r] * scale2 + kbv[r];
-              v = key > myq ? -INFINITY : v;
+              if (CAUSAL) v = key > myq ? -INFINITY : v;
               s[j][r] = v;
               tmax = fmaxf(tmax, v);
             }
@@ -738,9 +738,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2 + 1, lane), p1, o[dt], 0, 0, 0);
       }
     };
-    const int kt_plain = last_kt < P / 64 ? last_kt : P / 64;  // tiles [0, kt_plain): every key < P and < q0
+    // tiles [0, kt_plain): every key < P and (causal) < q0
+    const int kt_plain = CAUSAL ? (last_kt < P / 64 ? last_kt : P / 64) : (P / 64 <= last_kt ? P / 64 : last_kt + 1);
+    const int klast = CAUSAL ? q0 + 15 : S - 1;  // last key any row of the slice may attend to
     for (int kt = 0; kt < kt_plain; ++kt) tile(kt, 4, std::false_type{});
-    for (int kt = kt_plain; kt <= last_kt; ++kt) tile(kt, kt == last_kt ? ((q0 + 15 - kt * 64) >> 4) + 1 : 4, std::true_type{});
+    for (int kt = kt_plain; kt <= last_kt; ++kt) tile(kt, kt == last_kt ? ((klast - kt * 64) >> 4) + 1 : 4, std::true_type{});
     l = col_sum_sw(l);
     if (myq < S) {
       const float inv = 1.0f / l;
@@ -1079,6 +1081,13 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
   size_t bytes;
   if (g_attn_variant != 1 && attn_resident_fits(sh, &bytes)) {
     dim3 grid(sh.H, sh.B), block(256);
+    if (!sh.causal) {
+      if (sh.D != 64) { set_error("attn_fwd (bidirectional, bf16): head_dim %d has no MFMA kernel (CLIP towers use 64)", sh.D); return MAFED_EINVAL; }
+      set_lds_attr(attn_fwd_res_kernel<64, false>, bytes);
+      launch(K_ATTN_FWD, 2.0 * attn_fwd_flops(sh), attn_fwd_res_kernel<64, false>, grid, block, bytes, st, (const bf16_t*)qkv, sh, rc, rs, am,
+             (bf16_t*)out, lse);
+      return MAFED_OK;
+    }
     if (sh.D == 64) {
       set_lds_attr(attn_fwd_res_kernel<64>, bytes);
       launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_res_kernel<64>, grid, block, bytes, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
@@ -1088,6 +1097,7 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
     }
     return MAFED_OK;
   }
+  if (!sh.causal) { set_error("attn_fwd (bidirectional, bf16): S=%d D=%d does not fit the resident kernel", sh.S, sh.D); return MAFED_EINVAL; }
   dim3 grid((sh.S + 63) / 64, sh.H, sh.B), block(256);
   const size_t tb = (size_t)2 * 64 * sh.D * 2;
 #define MAFED_FWD_TILED(DD)                                                                                                       \

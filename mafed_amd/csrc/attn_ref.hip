@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void attn_ref_fwd_kernel(const T* __restrict__
   __builtin_amdgcn_wave_barrier();
   const float scale = rsqrtf((float)D);
   float m = -INFINITY;
-  for (int j = lane; j <= q; j += 64) {
+  const int jlast = sh.causal ? q : S - 1;  // bidirectional: every key
+  for (int j = lane; j <= jlast; j += 64) {
     float s = -INFINITY;
     if (key_valid(am, b, j, sh.P, sh.T)) {
       const T* kp = base + (int64_t)j * rstride + D;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_ref_fwd_kernel(const T* __restrict__
   }
   m = wave_max(m);
   float l = 0.f;
-  for (int j = lane; j <= q; j += 64) {
+  for (int j = lane; j <= jlast; j += 64) {
     const float p = expf(sc[j] - m);
     sc[j] = p;
     l += p;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_ref_fwd_kernel(const T* __restrict__
   T* op = out + ((int64_t)b * S + q) * H * D + (int64_t)h * D;
   for (int d = lane; d < D; d += 64) {
     float acc = 0.f;
-    for (int j = 0; j <= q; ++j) acc = fmaf(sc[j], Elem<T>::load(base + (int64_t)j * rstride + 2 * D + d), acc);
+    for (int j = 0; j <= jlast; ++j) acc = fmaf(sc[j], Elem<T>::load(base + (int64_t)j * rstride + 2 * D + d), acc);
     Elem<T>::store(op + d, acc * inv);
   }
   if (lane == 0) lse[((int64_t)b * H + h) * S + q] = m + logf(l);

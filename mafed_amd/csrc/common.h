@@ -176,6 +176,9 @@ __device__ __forceinline__ float gelu_erf_grad_fast(float x) {
   return gelu_erf_grad_fast2(v)[0];
 }
 
+// x * sigmoid(1.702 x): hidden_act "quick_gelu" of the OpenAI CLIP towers (transformers/activations.py QuickGELUActivation)
+__device__ __forceinline__ float quick_gelu(float x) { return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x)); }
+
 // modality class of a token row (mafed/methods/distillation.py:134-144): 0 = language (valid text), 1 = vision, 2 = none (pad)
 __device__ __forceinline__ int modality_class(int64_t row, int S, int P, int T, const int64_t* attention_mask) {
   const int64_t b = row / S;

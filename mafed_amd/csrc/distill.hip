@@ -161,6 +161,39 @@ __global__ __launch_bounds__(256) void distill_cls_bwd_kernel(const float* __res
   }
 }
 
+// Scalar tail of distill() (mafed/methods/distillation.py:105-122, 147-162) for all distilled layers in ONE launch:
+//   lang[l] = sums[l][0] / sums[l][2], vis[l] = sums[l][1] / sums[l][3]                      (masked means, :248)
+//   lw[l]   = n_lang / (n_lang + n_vis) | const | lang_coeff[l] ;  vw[l] = 1 - lw[l]         (distillation_loss_weights.py:71-79)
+//   per_layer[l] = lw * lang + vw * vis ;  loss = sum_l coeff[l] * per_layer[l]              (coeff = layer coefficient x distillation_coeff)
+// and the per-layer gradient coefficients the model's backward injects: inj[l] = {coeff lw / n_lang, coeff vw / n_vis, 0, 0}
+// (= d loss / d {sum_lang, sum_vis}).  One wave; layers strided over lanes; fixed-order reduction.
+__global__ __launch_bounds__(64) void distill_combine_kernel(const float* __restrict__ sums, int nl, const float* __restrict__ coeff, int mode,
+                                                             float lang_const, const float* __restrict__ lang_vec, float* __restrict__ loss,
+                                                             float* __restrict__ per_layer, float* __restrict__ modality,
+                                                             float* __restrict__ inj) {
+  const int lane = threadIdx.x;
+  const float n0 = sums[2], n1 = sums[3];  // counts of the first distilled layer (every layer sees the same masks)
+  float acc = 0.f;
+  for (int l = lane; l < nl; l += 64) {
+    const float4 s = load4(sums + 4 * l);
+    const float lang = s.x / s.z, vis = s.y / s.w;
+    float lw;
+    if (mode == 0) lw = n0 / (n0 + n1);
+    else if (mode == 1) lw = lang_const;
+    else lw = lang_vec[l];
+    const float vw = 1.0f - lw;
+    const float pl = lw * lang + vw * vis;
+    const float c = coeff[l];
+    per_layer[l] = pl;
+    modality[2 * l] = lang;
+    modality[2 * l + 1] = vis;
+    store4(inj + 4 * l, make_float4(c * lw / s.z, c * vw / s.w, 0.f, 0.f));
+    acc += c * pl;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) loss[0] = acc;
+}
+
 static int ds_blocks(int64_t rows) {
   int64_t nb = cdiv(rows, 4);
   if (nb > DS_MAX_BLOCKS) nb = DS_MAX_BLOCKS;
@@ -191,6 +224,19 @@ extern "C" int mafed_distill_fwd(const float* s, const float* t, const int64_t* 
   MAFED_CHECK_LAUNCH("distill_fwd");
   launch(K_SMALL, 0.0, distill_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, nblk, out4);
   MAFED_CHECK_LAUNCH("distill_fwd(finish)");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_distill_combine(const float* sums, int n_layers, const float* layer_coeff_dev, int modality_mode, float lang_weight,
+                                     const float* lang_weight_vec_dev, float* loss_out, float* per_layer_out, float* modality_out,
+                                     float* inject_out, void* stream) {
+  MAFED_CHECK_ARG(sums && layer_coeff_dev && loss_out && per_layer_out && modality_out && inject_out, "distill_combine: null pointer");
+  MAFED_CHECK_ARG(n_layers > 0 && modality_mode >= 0 && modality_mode <= 2, "distill_combine: n_layers=%d mode=%d", n_layers, modality_mode);
+  MAFED_CHECK_ARG(modality_mode != 2 || lang_weight_vec_dev, "distill_combine: adaptive weights need the per-layer vector");
+  MAFED_CHECK_ARG((((uintptr_t)sums | (uintptr_t)inject_out) & 15) == 0, "distill_combine: sums / inject must be 16-byte aligned");
+  launch(K_SMALL, 0.0, distill_combine_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, n_layers, layer_coeff_dev, modality_mode, lang_weight,
+         lang_weight_vec_dev, loss_out, per_layer_out, modality_out, inject_out);
+  MAFED_CHECK_LAUNCH("distill_combine");
   return MAFED_OK;
 }
 

@@ -106,6 +106,43 @@ static int grid_for(int64_t n, int per_thread = 1) {
   return (int)g;
 }
 
+// ---- frozen CLIP vision tower: patch embedding as a GEMM (CLIPVisionEmbeddings, clip:148-154, 202-218) ---------------------
+// im2col of a stride = kernel convolution: out[b * np + p][c * ps * ps + i * ps + j] = pix[b][c][py * ps + i][px * ps + j],
+// zero for the K .. Kpad-1 padding columns (Kpad a multiple of 64 lets the product take the LDS-DMA GEMM) and for pad rows.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ pix, int B, int C, int H, int W, int ps, int gw, int np, int K,
+                                                       int Kpad, int64_t rows_out, TO* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows_out * Kpad) return;
+  const int64_t row = idx / Kpad;
+  const int k = (int)(idx - row * Kpad);
+  float v = 0.f;
+  if (k < K && row < (int64_t)B * np) {
+    const int b = (int)(row / np), p = (int)(row - (int64_t)b * np);
+    const int py = p / gw, px = p - py * gw;
+    const int c = k / (ps * ps), r = k - c * ps * ps;
+    const int i = r / ps, j = r - i * ps;
+    v = Elem<TI>::load(pix + (((int64_t)b * C + c) * H + py * ps + i) * W + px * ps + j);
+  }
+  Elem<TO>::store(out + idx, v);
+}
+
+// tokens[b][0] = class_embedding + pos[0]; tokens[b][1 + p] = patch_emb[b * np + p] + pos[1 + p]  (fp32 residual stream)
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ pe, int64_t ld_pe, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, int B, int np, int h, float* __restrict__ out) {
+  const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t total = (int64_t)B * (np + 1) * h;
+  if (idx >= total) return;
+  const int64_t row = idx / h;
+  const int d = (int)(idx - row * h);
+  const int b = (int)(row / (np + 1)), s = (int)(row - (int64_t)b * (np + 1));
+  const float4 pv = load4(pos + (int64_t)s * h + d);
+  float4 x = s == 0 ? load4(cls + d) : load4(pe + ((int64_t)b * np + s - 1) * ld_pe + d);
+  x.x += pv.x; x.y += pv.y; x.z += pv.z; x.w += pv.w;
+  store4(out + idx, x);
+}
+
 }  // namespace mafed
 
 using namespace mafed;
@@ -180,5 +217,43 @@ extern "C" int mafed_colsum(const void* X, mafed_dtype dtype, int64_t M, int64_t
   if (dtype == MAFED_F32) launch(K_COLSUM, sbytes, colsum_kernel<float>, grid, block, 0, st, (const float*)X, M, N, ldx, out);
   else launch(K_COLSUM, sbytes, colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)X, M, N, ldx, out);
   MAFED_CHECK_LAUNCH("colsum");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_patchify(const void* pixels, mafed_dtype pix_dtype, int B, int C, int H, int W, int patch, int64_t rows_out, int k_pad,
+                              void* out, mafed_dtype out_dtype, void* stream) {
+  MAFED_CHECK_ARG(pixels && out, "patchify: null pointer");
+  MAFED_CHECK_ARG(B > 0 && C > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "patchify: image %dx%d is not a multiple of the patch %d", H, W, patch);
+  const int gw = W / patch, np = gw * (H / patch), K = C * patch * patch;
+  MAFED_CHECK_ARG(k_pad >= K && rows_out >= (int64_t)B * np, "patchify: k_pad=%d < %d or rows_out too small", k_pad, K);
+  const int64_t total = rows_out * k_pad;
+  dim3 grid((unsigned)cdiv(total, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  const double bytes = (double)B * C * H * W * (pix_dtype == MAFED_F32 ? 4.0 : 2.0) + (double)total * (out_dtype == MAFED_F32 ? 4.0 : 2.0);
+  if (pix_dtype == MAFED_F32 && out_dtype == MAFED_BF16)
+    launch(K_CAST, bytes, patchify_kernel<float, bf16_t>, grid, block, 0, st, (const float*)pixels, B, C, H, W, patch, gw, np, K, k_pad, rows_out, (bf16_t*)out);
+  else if (pix_dtype == MAFED_F32)
+    launch(K_CAST, bytes, patchify_kernel<float, float>, grid, block, 0, st, (const float*)pixels, B, C, H, W, patch, gw, np, K, k_pad, rows_out, (float*)out);
+  else if (out_dtype == MAFED_BF16)
+    launch(K_CAST, bytes, patchify_kernel<bf16_t, bf16_t>, grid, block, 0, st, (const bf16_t*)pixels, B, C, H, W, patch, gw, np, K, k_pad, rows_out, (bf16_t*)out);
+  else
+    launch(K_CAST, bytes, patchify_kernel<bf16_t, float>, grid, block, 0, st, (const bf16_t*)pixels, B, C, H, W, patch, gw, np, K, k_pad, rows_out, (float*)out);
+  MAFED_CHECK_LAUNCH("patchify");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_vit_assemble(const void* patch_emb, mafed_dtype pe_dtype, int64_t ld_pe, const float* class_embedding,
+                                  const float* position_embedding, int B, int num_patches, int h, float* tokens, void* stream) {
+  MAFED_CHECK_ARG(patch_emb && class_embedding && position_embedding && tokens, "vit_assemble: null pointer");
+  MAFED_CHECK_ARG(B > 0 && num_patches > 0 && h > 0 && h % 4 == 0 && ld_pe >= h && ld_pe % 4 == 0, "vit_assemble: bad shape");
+  const int64_t total4 = (int64_t)B * (num_patches + 1) * h / 4;
+  dim3 grid((unsigned)cdiv(total4, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  const double bytes = (double)B * (num_patches + 1) * h * (4.0 + (pe_dtype == MAFED_F32 ? 4.0 : 2.0));
+  if (pe_dtype == MAFED_F32)
+    launch(K_EMBED_FWD, bytes, vit_assemble_kernel<float>, grid, block, 0, st, (const float*)patch_emb, ld_pe, class_embedding, position_embedding, B, num_patches, h, tokens);
+  else
+    launch(K_EMBED_FWD, bytes, vit_assemble_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)patch_emb, ld_pe, class_embedding, position_embedding, B, num_patches, h, tokens);
+  MAFED_CHECK_LAUNCH("vit_assemble");
   return MAFED_OK;
 }

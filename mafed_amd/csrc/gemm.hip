@@ -956,7 +956,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
   MAFED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
   const int res1_bf16 = (epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
   epilogue &= ~MAFED_EPI_RES1_BF16;
-  MAFED_CHECK_ARG(epilogue >= MAFED_EPI_NONE && epilogue <= MAFED_EPI_GELU_BWD, "gemm: unknown epilogue %d", epilogue);
+  MAFED_CHECK_ARG(epilogue >= MAFED_EPI_NONE && epilogue <= MAFED_EPI_QUICK_GELU, "gemm: unknown epilogue %d", epilogue);
   MAFED_CHECK_ARG(epilogue != MAFED_EPI_GELU_BWD || aux, "gemm: GELU_BWD epilogue needs aux");
   MAFED_CHECK_ARG(beta == 0.f || c_dtype == MAFED_F32, "gemm: beta != 0 requires an fp32 C");
   MAFED_CHECK_ARG((((uintptr_t)C | (uintptr_t)aux | (uintptr_t)res1 | (uintptr_t)res2 | (uintptr_t)bias) & 7) == 0,

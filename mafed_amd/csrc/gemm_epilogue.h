@@ -28,6 +28,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmEpi& e, CT* __restrict
     if (e.aux) store4(reinterpret_cast<CT*>(e.aux) + off, v);
     if (FAST) v = make_float4(gelu_erf_fast(v.x), gelu_erf_fast(v.y), gelu_erf_fast(v.z), gelu_erf_fast(v.w));
     else v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+  } else if (e.mode == MAFED_EPI_QUICK_GELU) {
+    v = make_float4(quick_gelu(v.x), quick_gelu(v.y), quick_gelu(v.z), quick_gelu(v.w));
   } else if (e.mode == MAFED_EPI_GELU_BWD) {
     const float4 u = load4(reinterpret_cast<const CT*>(e.aux) + off);
     if (FAST) v = make_float4(v.x * gelu_erf_grad_fast(u.x), v.y * gelu_erf_grad_fast(u.y), v.z * gelu_erf_grad_fast(u.z), v.w * gelu_erf_grad_fast(u.w));
@@ -90,6 +92,9 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
       const f32x2 r = gelu_erf_fast2((f32x2){v[i], v[i + 1]});
       v[i] = r[0]; v[i + 1] = r[1];
     }
+  } else if (e.mode == MAFED_EPI_QUICK_GELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = quick_gelu(v[i]);
   } else if (e.mode == MAFED_EPI_GELU_BWD) {
     float u[8];
     load8(reinterpret_cast<const CT*>(e.aux) + off, u);

@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __res
   }
 }
 
-template <bool SHADOW>
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool SHADOW, bool ZERO_G = false>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float beta1,
                                                     float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                                                     const float* __restrict__ clip_dev, float grad_mul, bf16_t* __restrict__ p_bf16) {
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     store4(p + i * 4, pp); store4(m + i * 4, mm); store4(v + i * 4, vv);
     if (SHADOW) store4(p_bf16 + i * 4, pp);
+    if (ZERO_G) store4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));  // optimizer.zero_grad() of the next window, same pass
   }
   if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
     const int64_t i = n4 * 4 + threadIdx.x;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (wd > 0.f) x = x - decay * x;
     p[i] = x; m[i] = mk; v[i] = vk;
     if (SHADOW) p_bf16[i] = f32_to_bf16(x);
+    if (ZERO_G) g[i] = 0.f;
   }
 }
 
@@ -141,9 +143,8 @@ extern "C" int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, fl
   return MAFED_OK;
 }
 
-extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
-                                float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
-                                void* stream) {
+static int adamw_impl(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
+                      float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16, bool zero_g, void* stream) {
   MAFED_CHECK_ARG(p && g && m && v && lr_dev && n >= 0 && step >= 0, "adamw_step: bad arguments");
   MAFED_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step: buffers must be 16-byte aligned");
   MAFED_CHECK_ARG(!p_bf16 || ((uintptr_t)p_bf16 & 7) == 0, "adamw_step: p_bf16 must be 8-byte aligned");
@@ -155,13 +156,28 @@ extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, in
   hipStream_t st = as_stream(stream);
   int64_t nb = cdiv(n / 4 + 1, 256);
   if (nb > 4096) nb = 4096;
-  // algorithmic bytes: p, m, v read + written, g read (+ the bf16 shadow weight written) = 28 (30) bytes per parameter
-  if (p_bf16)
-    launch(K_ADAMW, (double)n * 30.0, adamw_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay,
-           (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16);
-  else
-    launch(K_ADAMW, (double)n * 28.0, adamw_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay,
-           (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)nullptr);
+  // algorithmic bytes: p, m, v read + written, g read (+ the bf16 shadow weight written, + the gradient zeroed) per parameter
+  const double bytes = (double)n * (28.0 + (p_bf16 ? 2.0 : 0.0) + (zero_g ? 4.0 : 0.0));
+#define MAFED_ADAMW(SH, ZG)                                                                                                          \
+  launch(K_ADAMW, bytes, adamw_kernel<SH, ZG>, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, \
+         (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16)
+  if (p_bf16 && zero_g) MAFED_ADAMW(true, true);
+  else if (p_bf16) MAFED_ADAMW(true, false);
+  else if (zero_g) MAFED_ADAMW(false, true);
+  else MAFED_ADAMW(false, false);
+#undef MAFED_ADAMW
   MAFED_CHECK_LAUNCH("adamw_step");
   return MAFED_OK;
+}
+
+extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                                float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
+                                void* stream) {
+  return adamw_impl(p, const_cast<float*>(g), m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, false, stream);
+}
+
+extern "C" int mafed_adamw_step_zero_grad(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                                          float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
+                                          void* stream) {
+  return adamw_impl(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, true, stream);
 }

@@ -50,32 +50,38 @@ class _DistillSumsFn(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-class _FusedDistillSumsFn(torch.autograd.Function):
-    """Same sums as _DistillSumsFn for the native model, but the backward materialises nothing: it leaves
-    d loss / d sums (one device row per layer) in the model's activation record and the model's own backward adds
+class _FusedDistillLossFn(torch.autograd.Function):
+    """The whole MSE distillation term of the native model as ONE node: the per-layer masked sums (started layer by layer
+    during the student forward, or computed here), then ``mafed_distill_combine`` -- masked means, modality weights, layer
+    coefficients and the scalar loss in one launch (the reference's per-layer Python loop, distillation.py:109-120, as ~12
+    torch kernels per step before).  The backward materialises nothing: it leaves d loss / d sums (one device row per layer,
+    scaled by the upstream gradient) in the model's activation record, and the model's own backward adds
     coef * 2/h * (x - teacher) to the residual-stream gradient inside the LayerNorm-backward kernel of that layer
-    (mafed_layernorm_bwd, teacher != NULL) -- no per-layer gradient tensor, no separate add / cast pass."""
+    (mafed_layernorm_bwd, teacher != NULL) -- no per-layer gradient tensor, no separate add / cast pass.
+    Outputs: (loss, per_layer [nl], modality [nl, 2]); only the loss is differentiable."""
 
     @staticmethod
-    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, early, *student):
+    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, early, coeffs, mode, lang_w, lang_vec, *student):
         nl = len(student)
         if early is not None:
             # the sums were started layer by layer during the student forward (FeatureDistillation._early_sums_hook)
-            out, ev = early
+            sums, ev = early
             torch.cuda.current_stream().wait_event(ev)
         else:
-            out = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
+            sums = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
             for l in range(nl):
-                ops.distill_fwd(student[l], teacher[l], attention_mask, P, False, out=out[l])
-        ctx.sv, ctx.layers, ctx.teacher = sv, list(layers), list(teacher)
-        return out
+                ops.distill_fwd(student[l], teacher[l], attention_mask, P, False, out=sums[l])
+        loss, per_layer, modality, inject = ops.distill_combine(sums, coeffs, mode, lang_w, lang_vec)
+        ctx.sv, ctx.layers, ctx.teacher, ctx.inject = sv, list(layers), list(teacher), inject
+        ctx.mark_non_differentiable(per_layer, modality)
+        return loss.reshape(()), per_layer, modality
 
     @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        ctx.sv["inject"] = {layer: (ctx.teacher[k], g[k]) for k, layer in enumerate(ctx.layers)}
+    def backward(ctx, g, _gp, _gm):
+        scaled = ctx.inject * g  # [nl, 4] x upstream d / d loss (1 / accumulate_grad_batches under the Trainer)
+        ctx.sv["inject"] = {layer: (ctx.teacher[k], scaled[k]) for k, layer in enumerate(ctx.layers)}
         ctx.sv = None
-        return (torch.zeros((), device=g.device), None, None, None, None, None, None) + (None,) * len(ctx.layers)
+        return (torch.zeros((), device=g.device),) + (None,) * (10 + len(ctx.layers))
 
 
 class _DistillClsFn(torch.autograd.Function):
@@ -207,6 +213,14 @@ class FeatureDistillation(CLStrategy):
         loss = dloss if loss is None else loss + dloss
         return loss, n_ex
 
+    def _cached(self, key, make):
+        """Constant device tensors of the step (mask pieces, the coefficient vector), built once per shape instead of per step."""
+        cache = self.__dict__.setdefault("_const_cache", {})
+        v = cache.get(key)
+        if v is None:
+            v = cache[key] = make()
+        return v
+
     def _install_early_sums(self, model, batch) -> bool:
         """Fused MSE path only: start each distilled layer's masked sums (one HBM-bound pass over student + teacher states)
         as soon as the student forward has produced that hidden state, on the teacher's stream, instead of running all of
@@ -293,7 +307,8 @@ class FeatureDistillation(CLStrategy):
         layers = self.loss_weights.get_distillation_layers()
         past = self._get_past_hidden_states(batch, n_hidden=max(layers) + 1)
         dev = output.hidden_states[0].device
-        coeffs = self.loss_weights.layer_coeff_vector(dev) * float(self.distillation_coeff)
+        base = self.loss_weights.layer_coeff_vector(dev)
+        coeffs = self._cached(("coeffs", id(base), float(self.distillation_coeff)), lambda: (base * float(self.distillation_coeff)).contiguous())
         P = self.num_vision_tokens
         am = batch["attention_mask"].to(dev, torch.int64).contiguous()
         if self._cls_distillation:
@@ -304,11 +319,11 @@ class FeatureDistillation(CLStrategy):
             self.last_modality_losses = None
         else:
             B, T = am.shape
-            lm = torch.zeros((B, T + P), dtype=am.dtype, device=dev)
-            lm[:, P:] = am
-            im = torch.zeros((B, T + P), dtype=am.dtype, device=dev)
-            im[:, :P] = 1
-            batch["lang_masks"], batch["image_masks"] = lm, im  # side effect kept (distillation.py:139,144)
+            # side effect kept (distillation.py:139,144): the masks the reference leaves in the batch dict
+            zeros_p = self._cached(("zp", B, P, str(dev)), lambda: torch.zeros((B, P), dtype=am.dtype, device=dev))
+            batch["lang_masks"] = torch.cat([zeros_p, am], dim=1)
+            batch["image_masks"] = self._cached(("im", B, P, T, str(dev)), lambda: torch.cat(
+                [torch.ones((B, P), dtype=am.dtype, device=dev), torch.zeros((B, T), dtype=am.dtype, device=dev)], dim=1))
             students = [output.hidden_states[l] for l in layers]
             teachers = [past[l] for l in layers]
             mctx = getattr(output, "mafed_ctx", None)
@@ -317,11 +332,15 @@ class FeatureDistillation(CLStrategy):
                 self._early = None
                 if early is not None and (early["layers"] != list(layers) or early["n"] != len(layers)):
                     early = None
-                sums = _FusedDistillSumsFn.apply(mctx[1], am, P, teachers, mctx[0], layers,
-                                                 (early["sums"], early["stream"].record_event()) if early is not None else None,
-                                                 *students)  # [nl, 4]
-            else:
-                sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
+                mode, lang_w, lang_vec = self.loss_weights.modality_mode(layers, dev)
+                loss, per_layer, modality = _FusedDistillLossFn.apply(
+                    mctx[1], am, P, teachers, mctx[0], layers, (early["sums"], early["stream"].record_event()) if early is not None else None,
+                    coeffs, mode, lang_w, lang_vec, *students)
+                self.last_modality_losses = modality
+                self.last_layer_losses = per_layer
+                self.step += 1
+                return loss
+            sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
             lang = sums[:, 0] / sums[:, 2]
             vis = sums[:, 1] / sums[:, 3]
             lw, vw = self.loss_weights.modality_weight_vectors(sums[0, 2].detach(), sums[0, 3].detach(), layers, dev)

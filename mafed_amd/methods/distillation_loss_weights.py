@@ -105,6 +105,19 @@ class DistillationWeights:
             raise NotImplementedError
         return lw, 1.0 - lw
 
+    def modality_mode(self, layers: Sequence[int], device):
+        """(mode, lang_weight, lang_weight_vec) for ``mafed_distill_combine``: 0 "equal" (from the token counts), 1 "balanced"
+        (constant), 2 "adaptive" (per-layer device vector) -- the same weights as ``modality_weight_vectors``."""
+        s = self._modality_weighing_strategy
+        if s == "equal":
+            return 0, 0.0, None
+        if s == "balanced":
+            return 1, float(self.lang_coeff), None
+        if s == "adaptive":
+            lw, _ = self.modality_weight_vectors(None, None, layers, device)
+            return 2, 0.0, lw
+        raise NotImplementedError
+
     def update_weights(self, model, dataloader, task_id) -> None:
         """Between tasks; only the adaptive strategy has state (running mean over tasks)."""
         if self._modality_weighing_strategy != "adaptive":

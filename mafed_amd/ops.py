@@ -246,6 +246,21 @@ def distill_bwd(s, t, attention_mask, P: int, coef: torch.Tensor, cosine: bool =
     return out
 
 
+def distill_combine(sums: torch.Tensor, layer_coeff: torch.Tensor, mode: int, lang_weight: float = 0.5,
+                    lang_weight_vec: Optional[torch.Tensor] = None):
+    """sums [nl,4] -> (loss [1], per_layer [nl], modality [nl,2], inject [nl,4]) in one launch (mafed_distill_combine)."""
+    nl = sums.shape[0]
+    assert sums.dtype == torch.float32 and sums.is_contiguous() and layer_coeff.dtype == torch.float32 and layer_coeff.numel() == nl
+    dev = sums.device
+    out = torch.empty(1 + nl + 2 * nl + 4 + 4 * nl, dtype=torch.float32, device=dev)  # one allocation; inject 16-byte aligned
+    loss, per_layer, modality = out[0:1], out[1:1 + nl], out[1 + nl:1 + 3 * nl].view(nl, 2)
+    o = (1 + 3 * nl + 3) // 4 * 4
+    inject = out[o:o + 4 * nl].view(nl, 4)
+    check(_lib.load().mafed_distill_combine(_ptr(sums), nl, _ptr(layer_coeff), int(mode), float(lang_weight), _ptr(lang_weight_vec), _ptr(loss),
+                                            _ptr(per_layer), _ptr(modality), _ptr(inject), _stream()), "mafed_distill_combine")
+    return loss, per_layer, modality, inject
+
+
 def distill_cls_fwd(s, t) -> torch.Tensor:
     B, S, h = s.shape
     out = torch.empty(1, dtype=torch.float32, device=s.device)
@@ -291,9 +306,11 @@ def gradnorm_clip(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor]
     return out2
 
 
-def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None) -> None:
-    check(_lib.load().mafed_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
-                                       int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
+def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None, zero_grad: bool = False) -> None:
+    """``zero_grad``: the kernel also writes zeros over ``g`` (the next window's optimizer.zero_grad(), same pass)."""
+    fn = _lib.load().mafed_adamw_step_zero_grad if zero_grad else _lib.load().mafed_adamw_step
+    check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
+             int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
 
 
 def optim_advance_(state: torch.Tensor, base_lr: float, warmup: int, total: int, beta1: float, beta2: float, hyper: torch.Tensor) -> None:

@@ -94,8 +94,9 @@ class FlatAdamW:
         self.advance()
         self.apply(grad_mul)
 
-    def apply(self, grad_mul: float = 1.0) -> None:
-        """Device half of a step (capturable): the AdamW kernels, reading this step's scalars from device memory."""
+    def apply(self, grad_mul: float = 1.0, zero_grads: bool = False) -> None:
+        """Device half of a step: the AdamW kernels, reading this step's scalars from device memory.  ``zero_grads``: the same
+        pass also zeroes the gradient buffer (optimizer.zero_grad() of the next window)."""
         m = self.model
         clip = self.clip_out if getattr(self, "_clip_pending", False) else None
         for grp in self.param_groups:
@@ -104,7 +105,7 @@ class FlatAdamW:
                 continue
             shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
             ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
-                            self.betas[0], self.betas[1], self.eps, grp["weight_decay"], 0, clip, grad_mul, shadow)
+                            self.betas[0], self.betas[1], self.eps, grp["weight_decay"], 0, clip, grad_mul, shadow, zero_grad=zero_grads)
         self._clip_pending = False
         if m.flat_shadow is not None:
             m._shadow_dirty = False
@@ -137,9 +138,7 @@ class FlatAdamW:
             for key, lo, hi, wd in self._chunks():
                 shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
                 ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
-                                self.betas[0], self.betas[1], self.eps, wd, 0, clip, grad_mul, shadow)
-                if zero_grads:
-                    m.flat_grads[lo:hi].zero_()
+                                self.betas[0], self.betas[1], self.eps, wd, 0, clip, grad_mul, shadow, zero_grad=zero_grads)
                 events[key] = stream.record_event()
         self._clip_pending = False
         if m.flat_shadow is not None:

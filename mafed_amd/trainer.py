@@ -99,8 +99,7 @@ class Trainer:
             if self.pipeline_optimizer:
                 self.model._param_events = self.optimizer.apply_pipelined(self._opt_stream)
             else:
-                self.optimizer.apply()
-                self.optimizer.zero_grad()
+                self.optimizer.apply(zero_grads=True)
             rec["stepped"] = True
         return rec
 

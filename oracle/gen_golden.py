@@ -508,6 +508,88 @@ def gen_decode_fixture(refs, seed=31):
     np.savez_compressed(os.path.join(OUT, "decode.npz"), **out)
 
 
+CLIP_TINY = {
+    # name: CLIP tower dims + the LM config it feeds (vision_hidden_size = the tower's hidden size, P = its patch count)
+    "c17": dict(hidden=128, heads=2, layers=3, ff=512, image=56, patch=14, B=2, lm=dict(h=128, H=2, L=2, V=384, T=6)),
+    "c50": dict(hidden=192, heads=3, layers=4, ff=640, image=98, patch=14, B=3, lm=dict(h=128, H=2, L=2, V=384, T=7)),
+}
+
+
+def clip_cfg(name):
+    from oracle import clip_vit_ref as C
+    t = CLIP_TINY[name]
+    return C.ClipVisionRefConfig(hidden_size=t["hidden"], num_hidden_layers=t["layers"], num_attention_heads=t["heads"],
+                                 intermediate_size=t["ff"], image_size=t["image"], patch_size=t["patch"])
+
+
+def gen_clip_fixture(refs, seed=41):
+    """Frozen CLIP tower: ``transformers.CLIPVisionModel`` built offline from a ``CLIPVisionConfig`` with the
+    build's deterministic weights, called exactly as the reference calls it -- through the reference's own
+    ``VLCLIPGPTNeoXForCausalLM.get_patch_embeddings`` / ``forward`` with ``pixel_values`` [B,3,H,W]."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel, GPTNeoXConfig
+    from oracle import clip_vit_ref as C
+    vp = refs[0]
+    for name, t in CLIP_TINY.items():
+        cc = clip_cfg(name)
+        csd = C.init_weights(cc, seed=seed)
+        hf = CLIPVisionModel(CLIPVisionConfig(hidden_size=cc.hidden_size, intermediate_size=cc.intermediate_size,
+                                              num_hidden_layers=cc.num_hidden_layers, num_attention_heads=cc.num_attention_heads,
+                                              image_size=cc.image_size, patch_size=cc.patch_size, num_channels=3, hidden_act="quick_gelu",
+                                              layer_norm_eps=cc.layer_norm_eps, attention_dropout=0.0))
+        hf.config._attn_implementation = "eager"
+        have = {k: tuple(v.shape) for k, v in hf.state_dict().items()}
+        # checkpoint names carry the ``vision_model.`` prefix (transformers 4.37.1, the hub files); the installed 5.x class
+        # registers the same tensors without it
+        strip = not any(k.startswith("vision_model.") for k in have)
+        fix = (lambda k: k[len("vision_model."):]) if strip else (lambda k: k)
+        for k, shp in C.param_shapes(cc):   # the tower's state-dict contract
+            assert have[fix(k)] == shp, (k, have.get(fix(k)), shp)
+        # the LM around it, through the reference class (CLIP branch of build_vision_encoder, vl_pythia.py:196-198)
+        lm = t["lm"]
+        cfg = R.RefConfig(vocab_size=lm["V"], hidden_size=lm["h"], num_hidden_layers=lm["L"], num_attention_heads=lm["H"],
+                          intermediate_size=4 * lm["h"], vision_hidden_size=cc.hidden_size, num_vision_tokens=cc.num_patches)
+        sd = R.init_weights(cfg, seed=seed + 2, bias_std=0.02, ln_jitter=0.05)
+        vp.build_vision_encoder = lambda nm: hf
+        hc = GPTNeoXConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                           num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                           rotary_pct=cfg.rotary_pct, rotary_emb_base=cfg.rotary_emb_base, max_position_embeddings=2048,
+                           layer_norm_eps=cfg.layer_norm_eps, tie_word_embeddings=False, hidden_dropout=0.0,
+                           attention_dropout=0.0, use_parallel_residual=True, attention_bias=True)
+        hc.vision_encoder_name = "openai/clip-tiny"
+        hc.select_layer = -2
+        hc.select_feature = "patch"
+        hc._attn_implementation = "eager"
+        # (VLCLIPGPTNeoXForCausalLM reads vision_encoder.config.hidden_size for CLIP towers, vl_pythia.py:219-224)
+        model = vp.VLCLIPGPTNeoXForCausalLM(hc)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        # (post_init() re-initialises every sub-module, the tower included: load the tower's weights afterwards)
+        missing, unexpected = hf.load_state_dict({fix(k): v for k, v in csd.items()}, strict=False)
+        assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+        assert model.vision_encoder is hf
+        model.eval()
+        pixels = C.make_pixels(cc, t["B"], seed + 1)
+        with torch.no_grad():
+            outs = hf(pixels, output_hidden_states=True)
+        assert len(outs.hidden_states) == cc.num_hidden_layers + 1
+        batch = R.make_batch(cfg, t["B"], lm["T"], seed=seed + 3, pad=True, n_answer=3)
+        with torch.no_grad():
+            feats = model.get_patch_embeddings(pixels)
+            out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], pixel_values=pixels,
+                        output_hidden_states=True, return_dict=True)
+        assert feats.shape == (t["B"], cc.num_patches, cc.hidden_size)
+        assert torch.equal(feats, outs.hidden_states[-2][:, 1:])
+        # restatement check while the reference is at hand
+        mine = C.patch_features(csd, pixels, cc)
+        err = float((mine - feats).abs().max())
+        assert err < 2e-5, err
+        g = {"seed": np.array(seed), "hidden0": np_(outs.hidden_states[0]), "features": np_(feats),
+             "penultimate_cls": np_(outs.hidden_states[-2][:, 0]), "loss": np_(out.loss), "logits_text": np_(out.logits[:, -lm["T"]:]),
+             "lm_hidden0": np_(out.hidden_states[0]), "weight_checksum": np.array(float(sum(v.double().abs().sum() for v in csd.values())))}
+        np.savez_compressed(os.path.join(OUT, f"clip_{name}.npz"), **g)
+        print("clip fixture", name, "S", cc.num_patches + 1, "features", tuple(feats.shape), "restatement err %.2e" % err, "loss %.5f" % float(out.loss))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import logging
@@ -523,6 +605,7 @@ def main():
     gen_optim_fixture(refs)
     gen_ewc_fixture(refs)
     gen_decode_fixture(refs)
+    gen_clip_fixture(refs)
 
 
 if __name__ == "__main__":
