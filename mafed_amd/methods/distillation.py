@@ -197,6 +197,12 @@ class FeatureDistillation(CLStrategy):
         batch = next(iter(self.mem_dataloader))
         n_ex = batch["input_ids"].size(0)
         do_replay = self.replay_coeff > 0 and self.task_id > 0
+        pv = batch.get("pixel_values")
+        if "patch_embeddings" not in batch and torch.is_tensor(pv) and pv.dim() == 4 and hasattr(model, "get_patch_embeddings"):
+            # images in the memory batch: ONE pass through the frozen tower serves student and teacher (upstream encodes the
+            # same images twice per step, distillation.py:91 and :222 -- the teacher's deep-copied tower holds the same weights)
+            with torch.no_grad():
+                batch["patch_embeddings"] = model.get_patch_embeddings(pv)
         if self.distillation_coeff != 0:
             # frozen-teacher forward on a second HIP stream, concurrent with the student's
             self._prefetch_teacher(batch, getattr(self.mem_dataloader, "last_ready_event", None))

@@ -169,7 +169,16 @@ class VLPythiaForCausalLM(nn.Module):
         self.flat_shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
         self._shadow_dirty = True
         self._build_tree(specs)
-        self.vision_encoder = _FrozenVision(vision_encoder)
+        from mafed_amd.vision import ClipVisionTower
+        if isinstance(vision_encoder, ClipVisionTower):
+            # native frozen tower: registered directly so that its tensors appear as ``vision_encoder.vision_model.*``, the names
+            # of the reference's state dict (CLIPVisionModel under ``vision_encoder``, vl_pythia.py:215)
+            if vision_encoder.config.hidden_size != config.vision_hidden_size or vision_encoder.config.num_patches != config.num_vision_tokens:
+                raise ValueError("vision tower (hidden %d, %d patches) does not match the config (vision_hidden_size %d, num_vision_tokens %d)" % (
+                    vision_encoder.config.hidden_size, vision_encoder.config.num_patches, config.vision_hidden_size, config.num_vision_tokens))
+            self.vision_encoder = vision_encoder
+        else:
+            self.vision_encoder = _FrozenVision(vision_encoder)
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._rot_cache: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
         # callable(i): fired when layer i's parameter gradients are final for this backward; i = L for the LM head /
@@ -261,7 +270,8 @@ class VLPythiaForCausalLM(nn.Module):
 
     def __deepcopy__(self, memo):
         """Teacher snapshot (mafed/methods/distillation.py:211-213): one flat device copy instead of a per-tensor walk."""
-        enc = getattr(self.vision_encoder, "encoder", None)
+        # (the frozen tower is shared, not copied: upstream's deepcopy duplicates ~0.3 B frozen parameters per teacher)
+        enc = self.vision_encoder if not isinstance(self.vision_encoder, _FrozenVision) else getattr(self.vision_encoder, "encoder", None)
         new = VLPythiaForCausalLM(self.config, self.compute_dtype, self.flat_params.device, vision_encoder=enc)
         with torch.no_grad():
             new.flat_params.copy_(self.flat_params)
@@ -288,7 +298,7 @@ class VLPythiaForCausalLM(nn.Module):
             self._view_cache.clear()
             self._side = None
             self._shadow_dirty = True
-            enc = getattr(self.vision_encoder, "encoder", None)
+            enc = self.vision_encoder if not isinstance(self.vision_encoder, _FrozenVision) else getattr(self.vision_encoder, "encoder", None)
             if enc is not None:
                 enc._apply(fn)
             return self
@@ -354,7 +364,8 @@ class VLPythiaForCausalLM(nn.Module):
 
     # ---- public forward ------------------------------------------------------------------------------------------
     def get_patch_embeddings(self, pixel_values: torch.Tensor) -> torch.Tensor:
-        """get_patch_embeddings + feature_select (mafed/model/vl_pythia.py:453-475); features pass through."""
+        """get_patch_embeddings + feature_select (mafed/model/vl_pythia.py:453-475): images [B,3,H,W] go through the frozen
+        tower (the native CLIP tower of mafed_amd.vision, or a user-supplied module); features pass through."""
         P, dv = self.config.num_vision_tokens, self.config.vision_hidden_size
         x = pixel_values
         if x.dim() == 4:

@@ -169,6 +169,37 @@ def attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, attention_mask, col
     return dqkv
 
 
+def attn_fwd_bidir(qkv: torch.Tensor, B: int, S: int, H: int, D: int, out: Optional[torch.Tensor] = None):
+    """Bidirectional attention of the CLIP vision tower: qkv [>= B*S, H*3*D] -> out [>= B*S, H*D] (rows past B*S untouched)."""
+    assert qkv.dim() == 2 and qkv.shape[1] == 3 * H * D and qkv.shape[0] >= B * S and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty((B * S, H * D), dtype=qkv.dtype, device=qkv.device)
+    assert out.dtype == qkv.dtype and out.shape[0] >= B * S and out.shape[1] == H * D and out.is_contiguous()
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mafed_attn_fwd_bidir(_ptr(qkv), _dt(qkv), B, S, H, D, _ptr(out), _ptr(lse), _stream()), "mafed_attn_fwd_bidir")
+    return out
+
+
+def patchify(pixels: torch.Tensor, patch: int, rows_out: int, k_pad: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """im2col of the patch convolution: pixels [B,C,H,W] -> [rows_out, k_pad] (zero padding rows / columns)."""
+    B, C, H, W = pixels.shape
+    assert pixels.is_contiguous()
+    out = torch.empty((rows_out, k_pad), dtype=out_dtype, device=pixels.device)
+    check(_lib.load().mafed_patchify(_ptr(pixels), _dt(pixels), B, C, H, W, int(patch), int(rows_out), int(k_pad), _ptr(out), _dt(out), _stream()),
+          "mafed_patchify")
+    return out
+
+
+def vit_assemble(patch_emb: torch.Tensor, class_embedding: torch.Tensor, position_embedding: torch.Tensor, B: int, num_patches: int, h: int,
+                 out: torch.Tensor) -> torch.Tensor:
+    """out[b, 0] = cls + pos[0]; out[b, 1 + p] = patch_emb[b * np + p] + pos[1 + p]   (fp32 rows of ``out`` [>= B*(np+1), h])"""
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= B * (num_patches + 1) and out.shape[1] == h
+    assert class_embedding.dtype == torch.float32 and position_embedding.dtype == torch.float32 and position_embedding.is_contiguous()
+    check(_lib.load().mafed_vit_assemble(_ptr(patch_emb), _dt(patch_emb), patch_emb.stride(0), _ptr(class_embedding), _ptr(position_embedding), B,
+                                         num_patches, h, _ptr(out), _stream()), "mafed_vit_assemble")
+    return out
+
+
 def attn_decode(qkv_prefix: torch.Tensor, S0: int, qkv_new: torch.Tensor, t: int, B: int, H: int, D: int, rot: int, cos, sin,
                 attention_mask: torch.Tensor) -> torch.Tensor:
     """One decode step of attention: query = row t of ``qkv_new`` [B,cap,3*H*D], keys = the prefill's ``qkv_prefix``

@@ -94,3 +94,29 @@ def decode_setup(case):
     eos = int(g[f"{case}/eos"])
     return (cfg, sd, batch, None if eos < 0 else eos, int(g[f"{case}/max_new"]), torch.from_numpy(g[f"{case}/tokens"]),
             torch.from_numpy(g[f"{case}/step_logits"]), torch.from_numpy(g[f"{case}/top2_gap"]))
+
+
+CLIP_TINY = {  # mirrors oracle/gen_golden.py::CLIP_TINY
+    "c17": dict(hidden=128, heads=2, layers=3, ff=512, image=56, patch=14, B=2, lm=dict(h=128, H=2, L=2, V=384, T=6)),
+    "c50": dict(hidden=192, heads=3, layers=4, ff=640, image=98, patch=14, B=3, lm=dict(h=128, H=2, L=2, V=384, T=7)),
+}
+
+
+def clip_setup(name):
+    """Inputs of oracle/gen_golden.py::gen_clip_fixture: (tower cfg, tower weights, pixels, LM cfg, LM weights, text batch, golden)."""
+    from oracle import clip_vit_ref as C
+    g = load_golden(f"clip_{name}.npz")
+    t = CLIP_TINY[name]
+    seed = int(g["seed"])
+    cc = C.ClipVisionRefConfig(hidden_size=t["hidden"], num_hidden_layers=t["layers"], num_attention_heads=t["heads"],
+                               intermediate_size=t["ff"], image_size=t["image"], patch_size=t["patch"])
+    csd = C.init_weights(cc, seed=seed)
+    chk = float(sum(v.double().abs().sum() for v in csd.values()))
+    assert abs(chk - float(g["weight_checksum"])) < 1e-6 * chk, "deterministic CLIP weight generator drifted"
+    pixels = C.make_pixels(cc, t["B"], seed + 1)
+    lm = t["lm"]
+    cfg = R.RefConfig(vocab_size=lm["V"], hidden_size=lm["h"], num_hidden_layers=lm["L"], num_attention_heads=lm["H"],
+                      intermediate_size=4 * lm["h"], vision_hidden_size=cc.hidden_size, num_vision_tokens=cc.num_patches)
+    sd = R.init_weights(cfg, seed=seed + 2, bias_std=0.02, ln_jitter=0.05)
+    batch = R.make_batch(cfg, t["B"], lm["T"], seed=seed + 3, pad=True, n_answer=3)
+    return cc, csd, pixels, cfg, sd, batch, g

@@ -210,3 +210,24 @@ def test_greedy_decode(case):
     if case == "t64_eos":
         first = (ids[0, T:] == eos).nonzero()[0, 0]
         assert bool((ids[0, T + int(first):] == eos).all())          # a finished row keeps emitting pad (= eos)
+
+
+@pytest.mark.parametrize("name", ["c17", "c50"])
+def test_clip_tower_restatement(name):
+    """oracle/clip_vit_ref.py against what transformers.CLIPVisionModel produced through the reference's own
+    get_patch_embeddings / forward (fixtures of oracle/gen_golden.py::gen_clip_fixture)."""
+    from oracle import clip_vit_ref as C
+    from tests.helpers import clip_setup
+    cc, csd, pixels, cfg, sd, batch, g = clip_setup(name)
+    hs = C.hidden_states(csd, pixels, cc, n_layers=cc.layers_run)
+    assert len(hs) == cc.num_hidden_layers  # hidden_states[-2] of L + 1 entries
+    close(hs[0], g["hidden0"], 2e-5)
+    close(hs[-1][:, 0], g["penultimate_cls"], 2e-5)
+    feats = C.patch_features(csd, pixels, cc)
+    close(feats, g["features"], 2e-5)
+    # the LM on top of those features (pixel_values -> tower -> projector -> decoder -> loss)
+    out = R.forward(sd, dict(batch, patch_embeddings=feats), cfg)
+    close(out.loss, float(g["loss"]), 2e-5)
+    T = batch["input_ids"].shape[1]
+    close(out.logits[:, -T:], g["logits_text"], 2e-5)
+    close(out.hidden_states[0], g["lm_hidden0"], 2e-5)

@@ -33,7 +33,10 @@ for pv in os.environ.get("GEMM_BENCH_PRE", "").split(","):
         lib.mafed_gemm_set_variant(int(pv))   # persistent knobs (split / group / desync ...), applied before the sweep
 g = torch.Generator(device=dev).manual_seed(0)
 res = {}
+ONLY = [x for x in os.environ.get("GEMM_BENCH_ONLY", "").split(",") if x]
 for name, tA, tB, m, n, k, od in SHAPES:
+    if ONLY and name.split()[0] not in ONLY:
+        continue
     A = torch.randn((k, m) if tA else (m, k), device=dev, generator=g).to(torch.bfloat16)
     B = torch.randn((n, k) if tB else (k, n), device=dev, generator=g).to(torch.bfloat16)
     out = torch.zeros((m, n), dtype=od, device=dev)
