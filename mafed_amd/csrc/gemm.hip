@@ -12,8 +12,12 @@
 //  output row: 8/16-byte epilogue stores, float4 bias/residual loads.
 //
 //  fp32 path (parity mode, 1e-3 gate of the north star): plain FMA tile kernel, exact fp32 products.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "gemm_epilogue.h"
+#include "gemm_tiles.h"
 
 #ifndef MAFED_GEMM_SPREAD_DMA
 #define MAFED_GEMM_SPREAD_DMA 0  // measured twice (also with a hand-ordered, fence-pinned row schedule): a DMA piece between MFMA rows is 1.1-1.6x SLOWER than the burst (fc1 114 -> 177 us)
@@ -77,17 +81,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int transA, int transB, i
 // ------------------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int TILE_BYTES = 128 * 64 * 2;              // one operand tile, either image: 16 KiB
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_BYTES;    // 2 stages x (A + B) = 64 KiB -> 2 blocks / CU
-
-// KC image: [128 rows][64 k] bf16, 128-byte rows, 16-byte chunk index XORed with (row>>1)&7:
-// a ds_read_b128 lane group (16 rows x one chunk, two rows per 256-byte bank row) then touches 16 distinct slots.
-__device__ __forceinline__ int lds_off_kc(int row, int kchunk) { return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4); }
-// KS image: [64 k][128 rows] bf16, 256-byte k-rows (= all 64 banks), 32-byte chunk (16 rows) index XORed with
-// f(k) = (k&3) | ((k>>3)&1)<<2: the 8 k-rows a 32-lane half reads in one ds_read_b64_tr_b16 get 8 distinct chunks.
-__device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
-__device__ __forceinline__ int lds_off_ks(int k, int r16, int byte_in_32) { return k * 256 + ((r16 ^ ks_f(k)) << 5) + byte_in_32; }
 
 // global -> registers for one 128 x 64 operand tile (4 x 16 B per thread), zero-filled out of range
 template <bool KS>
@@ -221,48 +217,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(int64_t M, int64_t N,
 // SOURCE address (cdna_hip_programming rule 21).  Two LDS stages, one barrier per K-tile: the DMA of tile t+1 is
 // issued right after the barrier that publishes tile t and flies under tile t's MFMAs.
 // ------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef const __attribute__((address_space(1))) void* glb_void_ptr;
-
-// per-lane source element offset (without the k-tile advance) of DMA instruction j of an R-row operand tile
-template <bool KS, int R>
-__device__ __forceinline__ int64_t glds_src_off(int j, int lane, int64_t ld, int64_t r0) {
-  if (!KS) {
-    const int row = j * 8 + (lane >> 3), phys = lane & 7;
-    const int logical = phys ^ ((row >> 1) & 7);
-    return (r0 + row) * ld + logical * 8;
-  } else {
-    constexpr int RB = 2 * R;                  // bytes per k-row of the image
-    const int p = j * 1024 + lane * 16;
-    const int k = p / RB, within = p % RB;
-    const int logical16 = (within >> 5) ^ (ks_f(k) & (R / 16 - 1));
-    return (int64_t)k * ld + r0 + logical16 * 16 + ((within >> 4) & 1) * 8;
-  }
-}
-// [k][R rows] image: 32-byte chunk index XOR f(k), masked to the R/16 chunks of a k-row (R = 64: 2-way conflicts remain)
-template <int R>
-__device__ __forceinline__ int lds_off_ks_r(int k, int r16, int byte_in_32) {
-  return k * (2 * R) + ((r16 ^ (ks_f(k) & (R / 16 - 1))) << 5) + byte_in_32;
-}
-
-template <bool KS, int R>
-__device__ __forceinline__ bf16x8 glds_read_frag(const char* __restrict__ img, int rt, int ks, int lane) {
-  if (!KS) {
-    const int row = rt * 16 + (lane & 15);
-    return *reinterpret_cast<const bf16x8*>(img + lds_off_kc(row, ks * 4 + (lane >> 4)));
-  } else {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int ka = ks * 32 + 8 * g + q, kb = ka + 4;
-    typedef __attribute__((address_space(3))) bf16x4* lptr;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks_r<R>(ka, rt, p * 8)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks_r<R>(kb, rt, p * 8)));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  }
-}
-
 #ifdef MAFED_GEMM_TRACE
 // Tuning builds only (tools/gemm_trace.py): per-block phase timestamps {hw_id, xcc_id, start, first tile landed, loop end,
 // block end} on the 100 MHz s_memrealtime clock, to see how the blocks that share a CU line up in time.
@@ -920,9 +874,13 @@ using namespace mafed;
 
 // test / tuning hook: 0 = automatic, 1 = force the register-staged kernel
 static int g_gemm_variant = 0;
+static int g_gemm_persist = 1;  // 400 = off, 401 = on: persistent deferred-store kernel for bf16 outputs with >= 2 tiles per resident block
+static int g_gemm_persist_grid = 0;  // 500 + n: resident blocks of the persistent kernel (0 = two per CU); tests shrink it to reach it with small shapes
 static int g_gemm_big = 0;    // 288x256 configuration in automatic mode (200 = off, 201 = on): faster alone, slower beside the side streams
 static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
 extern "C" int mafed_gemm_set_variant(int v) {
+  if (v >= 500) { g_gemm_persist_grid = v - 500; return MAFED_OK; }
+  if (v >= 400) { g_gemm_persist = v - 400; return MAFED_OK; }
   if (v >= 300) { g_gemm_group_m = v - 300 > 0 ? v - 300 : 1; return MAFED_OK; }
   if (v >= 200) { g_gemm_big = v - 200; return MAFED_OK; }
   if (v >= 100) { g_gemm_split = v - 100; return MAFED_OK; }  // 100 = automatic split-K, 101 = off, 100 + n = force n
@@ -1029,6 +987,27 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? (nkt >= 512 ? 8 : 4) : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
     while (ns > 1 && nkt / ns < 8) ns >>= 1;
     g_gemm_nsplit = ns;
+  }
+  if ((cfg == 11 || cfg == 17) && g_gemm_persist && (g_gemm_variant == 0 || g_gemm_variant == 21 || g_gemm_variant == 27) && c_dtype == MAFED_BF16 && beta == 0.f && !res1 && !res2 && !a_ks) {
+    // >= 2 tiles per resident block (two blocks per CU): the stores of tile i run under the K loop of tile i + 1
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int grid = g_gemm_persist_grid > 0 ? g_gemm_persist_grid : 2 * n_cu;
+    const int tmr = cfg == 11 ? 144 : 192, mtr = cfg == 11 ? 9 : 6;
+    const int64_t ntiles = (M / tmr) * (N / 128);
+    GemmEpi pe = epi;
+    pe.colsum = colsum;
+    if ((ntiles >= 2 * grid || g_gemm_persist_grid > 0) && K / 64 >= mtr && gemm_persist_ok(M, N, K, lda, ldb, b_ks, pe)) {
+      epi.colsum = colsum;
+      rc = gemm_persist_launch(cfg, b_ks, M, N, K, A, lda, B, ldb, C, epi, grid, g_gemm_group_m, st);
+      if (rc != MAFED_OK) return rc;
+      MAFED_CHECK_LAUNCH("gemm(bf16, persistent)");
+      return MAFED_OK;
+    }
   }
   if (cfg >= 0) {
     const bool fused_colsum = colsum && g_gemm_nsplit == 1 && (cfg == 0 || cfg == 11 || cfg == 16 || cfg == 17);

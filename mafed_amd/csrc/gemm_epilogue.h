@@ -158,6 +158,11 @@ __device__ __forceinline__ void colsum_flush(float (&cs)[8], float* __restrict__
   }
 }
 
+// persistent deferred-store kernel (gemm_persist.hip)
+bool gemm_persist_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, bool b_ks, const GemmEpi& epi);
+int gemm_persist_launch(int cfg, bool b_ks, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                        const GemmEpi& epi, int grid, int group_m, hipStream_t st);
+
 // decode-path product (gemm_skinny.hip)
 bool gemm_skinny_ok(int transA, int transB, int64_t M, int64_t N, int64_t K, float beta, const void* colsum);
 int gemm_skinny_launch(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, mafed_dtype c_dtype,
