@@ -262,8 +262,7 @@ const char* mafed_prof_tag_name(int tag);
 
 /* test / tuning hook: 0 = automatic kernel choice, 1 = force the register-staged MFMA GEMM (the ragged-shape kernel),
  * 10 + c = force LDS-DMA tile configuration c; 100 = automatic split-K for accumulate-only outputs, 101 = no split-K,
- * 100 + n = force n K-splits where legal; 400 / 401 = persistent deferred-store kernel off / on (default on: bf16 outputs with at
- * least two tiles per resident block); 500 + n = its number of resident blocks (0 = two per CU) */
+ * 100 + n = force n K-splits where legal */
 int mafed_gemm_set_variant(int variant);
 
 /* test / tuning hook: 0 = automatic (one-block-per-head "resident" kernels when K/V fit in LDS), 1 = tiled kernels only */

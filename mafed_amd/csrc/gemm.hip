@@ -874,13 +874,9 @@ using namespace mafed;
 
 // test / tuning hook: 0 = automatic, 1 = force the register-staged kernel
 static int g_gemm_variant = 0;
-static int g_gemm_persist = 1;  // 400 = off, 401 = on: persistent deferred-store kernel for bf16 outputs with >= 2 tiles per resident block
-static int g_gemm_persist_grid = 0;  // 500 + n: resident blocks of the persistent kernel (0 = two per CU); tests shrink it to reach it with small shapes
 static int g_gemm_big = 0;    // 288x256 configuration in automatic mode (200 = off, 201 = on): faster alone, slower beside the side streams
 static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
 extern "C" int mafed_gemm_set_variant(int v) {
-  if (v >= 500) { g_gemm_persist_grid = v - 500; return MAFED_OK; }
-  if (v >= 400) { g_gemm_persist = v - 400; return MAFED_OK; }
   if (v >= 300) { g_gemm_group_m = v - 300 > 0 ? v - 300 : 1; return MAFED_OK; }
   if (v >= 200) { g_gemm_big = v - 200; return MAFED_OK; }
   if (v >= 100) { g_gemm_split = v - 100; return MAFED_OK; }  // 100 = automatic split-K, 101 = off, 100 + n = force n
@@ -987,27 +983,6 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? (nkt >= 512 ? 8 : 4) : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
     while (ns > 1 && nkt / ns < 8) ns >>= 1;
     g_gemm_nsplit = ns;
-  }
-  if ((cfg == 11 || cfg == 17) && g_gemm_persist && (g_gemm_variant == 0 || g_gemm_variant == 21 || g_gemm_variant == 27) && c_dtype == MAFED_BF16 && beta == 0.f && !res1 && !res2 && !a_ks) {
-    // >= 2 tiles per resident block (two blocks per CU): the stores of tile i run under the K loop of tile i + 1
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    const int grid = g_gemm_persist_grid > 0 ? g_gemm_persist_grid : 2 * n_cu;
-    const int tmr = cfg == 11 ? 144 : 192, mtr = cfg == 11 ? 9 : 6;
-    const int64_t ntiles = (M / tmr) * (N / 128);
-    GemmEpi pe = epi;
-    pe.colsum = colsum;
-    if ((ntiles >= 2 * grid || g_gemm_persist_grid > 0) && K / 64 >= mtr && gemm_persist_ok(M, N, K, lda, ldb, b_ks, pe)) {
-      epi.colsum = colsum;
-      rc = gemm_persist_launch(cfg, b_ks, M, N, K, A, lda, B, ldb, C, epi, grid, g_gemm_group_m, st);
-      if (rc != MAFED_OK) return rc;
-      MAFED_CHECK_LAUNCH("gemm(bf16, persistent)");
-      return MAFED_OK;
-    }
   }
   if (cfg >= 0) {
     const bool fused_colsum = colsum && g_gemm_nsplit == 1 && (cfg == 0 || cfg == 11 || cfg == 16 || cfg == 17);

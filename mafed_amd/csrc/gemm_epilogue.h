@@ -63,32 +63,17 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
   v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
   v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
-// tuning builds (tools/build_variant.sh): streaming hint on the epilogue's global stores
-#ifndef MAFED_NT_AUX
-#define MAFED_NT_AUX 0
-#endif
-#ifndef MAFED_NT_C
-#define MAFED_NT_C 0
-#endif
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ void st16(void* p, uint4 r) {
-  if (NT) __builtin_nontemporal_store((u32x4_t){r.x, r.y, r.z, r.w}, reinterpret_cast<u32x4_t*>(p));
-  else *reinterpret_cast<uint4*>(p) = r;
-}
-template <bool NT = false>
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-  st16<NT>(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
-  st16<NT>(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+  store4(p, make_float4(v[0], v[1], v[2], v[3]));
+  store4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
 }
-template <bool NT = false>
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   uint4 r;
   r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
   r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
   r.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
   r.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-  st16<NT>(p, r);
+  *reinterpret_cast<uint4*>(p) = r;
 }
 
 template <typename CT>
@@ -101,7 +86,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if (e.mode == MAFED_EPI_GELU) {
-    if (e.aux) store8<MAFED_NT_AUX != 0>(reinterpret_cast<CT*>(e.aux) + off, v);
+    if (e.aux) store8(reinterpret_cast<CT*>(e.aux) + off, v);
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
       const f32x2 r = gelu_erf_fast2((f32x2){v[i], v[i + 1]});
@@ -138,7 +123,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += e.beta * c[i];
   }
-  store8<MAFED_NT_C != 0>(C + off, v);
+  store8(C + off, v);
 }
 
 // Fused column sums of the stored tile: cs[i] holds this lane's partial for column 8*(lane % JL)+i over the rows it
@@ -157,11 +142,6 @@ __device__ __forceinline__ void colsum_flush(float (&cs)[8], float* __restrict__
     for (int i = 0; i < 8; ++i) atomicAdd(colsum + ncol0 + 8 * lane + i, cs[i]);
   }
 }
-
-// persistent deferred-store kernel (gemm_persist.hip)
-bool gemm_persist_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, bool b_ks, const GemmEpi& epi);
-int gemm_persist_launch(int cfg, bool b_ks, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
-                        const GemmEpi& epi, int grid, int group_m, hipStream_t st);
 
 // decode-path product (gemm_skinny.hip)
 bool gemm_skinny_ok(int transA, int transB, int64_t M, int64_t N, int64_t K, float beta, const void* colsum);

@@ -1,4 +1,4 @@
-// LDS operand images of the LDS-DMA MFMA GEMM kernels (gemm.hip, gemm_persist.hip): swizzles, per-lane DMA source addresses, fragment reads.
+// LDS operand images of the LDS-DMA MFMA GEMM kernels (gemm.hip): swizzles, per-lane DMA source addresses, fragment reads.
 #pragma once
 #include "common.h"
 

@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from mafed_amd import _lib
-from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_RES1_BF16, F32, check  # noqa: F401
+from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QUICK_GELU, EPI_RES1_BF16, F32, check  # noqa: F401
 
 
 def _dt(t: torch.Tensor) -> int:

@@ -196,74 +196,6 @@ def test_gemm_fused_colsum(dt, M, N, K, epi):
     assert err <= bound, (err, bound)
 
 
-@pytest.mark.parametrize("variant", [21, 27])
-@pytest.mark.parametrize("tB", [True, False])
-@pytest.mark.parametrize("grid", [4, 5, 16])
-def test_gemm_persistent_deferred_stores(variant, tB, grid):
-    """The persistent kernel (a block walks several tiles; a finished tile is stored from registers under the next tile's K loop)
-    against the one-tile-per-block kernel on the same operands: plain / bias, GELU + saved pre-activation, GELU' (+ fused column
-    sums), quick-GELU.  ``grid`` resident blocks over 16 tiles: 4 / 3-4 / 1 tiles per block (the last = every tile flushed at once)."""
-    ops = _ops()
-    from mafed_amd import _lib
-    lib = _lib.load()
-    M, N, K = 576, 512, 640
-    g = torch.Generator().manual_seed(11 + variant)
-    A = _int_mat((M, K), g).to(DEV, torch.bfloat16)
-    W = _int_mat((N, K) if tB else (K, N), g).to(DEV, torch.bfloat16)
-    bias = torch.randint(-4, 5, (N,), generator=g).float().to(DEV)
-    u = (torch.randn(M, N, generator=g) * 1.5).to(DEV, torch.bfloat16)
-
-    def run(persist, **kw):
-        lib.mafed_gemm_set_variant(variant)
-        lib.mafed_gemm_set_variant(401 if persist else 400)
-        lib.mafed_gemm_set_variant(500 + (grid if persist else 0))
-        try:
-            return ops.gemm(A, W, False, tB, **kw)
-        finally:
-            lib.mafed_gemm_set_variant(0)
-            lib.mafed_gemm_set_variant(401)
-            lib.mafed_gemm_set_variant(500)
-
-    # integer operands: exact accumulators, so the plain and the bias product must agree bit for bit with the old kernel
-    assert torch.equal(run(True), run(False))
-    assert torch.equal(run(True, bias=bias), run(False, bias=bias))
-    ref = _gemm_ref(A.float().cpu(), W.float().cpu(), False, tB)
-    assert maxerr(run(True).float(), ref.to(torch.bfloat16).float()) == 0.0
-    # GELU: aux = the bf16 pre-activation (identical), C = gelu(aux) (the old kernel applies GELU before rounding: <= 1 bf16 ulp apart)
-    A2 = (A.float() * 0.0625).to(torch.bfloat16)
-    aux_p, aux_o = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-
-    def run2(persist, **kw):
-        lib.mafed_gemm_set_variant(variant)
-        lib.mafed_gemm_set_variant(401 if persist else 400)
-        lib.mafed_gemm_set_variant(500 + (grid if persist else 0))
-        try:
-            return ops.gemm(A2, W, False, tB, **kw)
-        finally:
-            lib.mafed_gemm_set_variant(0)
-            lib.mafed_gemm_set_variant(401)
-            lib.mafed_gemm_set_variant(500)
-
-    yp = run2(True, bias=bias, epilogue=ops.EPI_GELU, aux=aux_p)
-    yo = run2(False, bias=bias, epilogue=ops.EPI_GELU, aux=aux_o)
-    assert torch.equal(aux_p, aux_o)
-    assert_close(yp.float(), F.gelu(aux_p.float().cpu().double()), 1e-2, "gelu(aux)")
-    assert_close(yp.float(), yo.float().cpu().double(), 1e-2, "gelu vs one-tile-per-block kernel")
-    yq = run2(True, bias=bias, epilogue=ops.EPI_QUICK_GELU)
-    pre = aux_p.float().cpu().double()
-    assert_close(yq.float(), pre * torch.sigmoid(1.702 * pre), 1e-2, "quick gelu")
-    # GELU' with and without the fused column sums
-    dp = run2(True, epilogue=ops.EPI_GELU_BWD, aux=u)
-    do = run2(False, epilogue=ops.EPI_GELU_BWD, aux=u)
-    assert_close(dp.float(), do.float().cpu().double(), 1e-2, "gelu' vs one-tile-per-block kernel")
-    cs = torch.full((N,), 0.75, dtype=torch.float32, device=DEV)
-    dc = run2(True, epilogue=ops.EPI_GELU_BWD, aux=u, colsum=cs)
-    assert torch.equal(dc, dp), "the colsum entry point must not change C"
-    want = dc.double().sum(0) + 0.75
-    bound = dc.double().abs().sum(0).max().item() * 2.0 ** -8 + 1e-3
-    assert (cs.double() - want).abs().max().item() <= bound
-
-
 def test_gemm_rejects_bad_arguments():
     ops = _ops()
     from mafed_amd._lib import MafedHipError
