@@ -253,11 +253,11 @@ int mafed_attn_fwd_bidir(const void* qkv, mafed_dtype dtype, int B, int S, int H
  * (hipExtLaunchKernelGGL): the elapsed time of a pair is that dispatch's own execution time on the GPU -- what
  * `rocprofv3 --kernel-trace` reports -- independent of how long the launch sat queued behind other streams.  After the caller
  * has synchronised the device, mafed_prof_collect() returns, in launch order, each record's kernel tag, its algorithmic work
- * (flops for the MFMA kernels, bytes for the HBM-bound ones) and its duration in ms (host pointers),
- * and the number of records held.  mafed_prof_tag_name() names a tag.  Launches beyond max_records are not recorded. */
+ * (flops for the MFMA kernels, bytes for the HBM-bound ones), its duration in ms and (optionally) its start
+ * time in ms relative to the first record's start (host pointers, any may be NULL), and the number of records held.  mafed_prof_tag_name() names a tag.  Launches beyond max_records are not recorded. */
 int mafed_prof_begin(int max_records);
 int mafed_prof_end(void);
-int mafed_prof_collect(int* tags_host, double* work_host, float* ms_host, int max);
+int mafed_prof_collect(int* tags_host, double* work_host, float* ms_host, float* start_ms_host, int max);
 const char* mafed_prof_tag_name(int tag);
 
 /* test / tuning hook: 0 = automatic kernel choice, 1 = force the register-staged MFMA GEMM (the ragged-shape kernel),

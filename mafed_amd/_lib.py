@@ -60,7 +60,7 @@ SIGNATURES = {
     "mafed_attn_fwd_bidir": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mafed_prof_begin": (_i, [_i]),
     "mafed_prof_end": (_i, []),
-    "mafed_prof_collect": (_i, [_p, _p, _p, _i]),
+    "mafed_prof_collect": (_i, [_p, _p, _p, _p, _i]),
     "mafed_prof_tag_name": (C.c_char_p, [_i]),
 }
 

@@ -64,7 +64,7 @@ extern "C" int mafed_prof_end(void) {
 }
 
 // The caller has synchronised the device.  Fills up to `max` records in launch order and returns how many a profile holds.
-extern "C" int mafed_prof_collect(int* tags, double* work, float* ms, int max) {
+extern "C" int mafed_prof_collect(int* tags, double* work, float* ms, float* start_ms, int max) {
   using namespace mafed;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   const int n = (int)g_prof_recs.size();
@@ -74,6 +74,11 @@ extern "C" int mafed_prof_collect(int* tags, double* work, float* ms, int max) {
     if (tags) tags[i] = g_prof_recs[i].tag;
     if (work) work[i] = g_prof_recs[i].work;
     if (ms) ms[i] = t;
+    if (start_ms) {  // launch time line: start of record i relative to the start of the first record
+      float s0 = 0.f;
+      if (i > 0 && hipEventElapsedTime(&s0, g_prof_recs[0].e0, g_prof_recs[i].e0) != hipSuccess) s0 = -1.f;
+      start_ms[i] = s0;
+    }
   }
   (void)hipGetLastError();
   return n;

@@ -30,6 +30,7 @@ class KernelProfile:
     def __init__(self, max_records: int = 1 << 16):
         self.max_records = int(max_records)
         self._records = None
+        self.starts_ms: List[float] = []  # start of every record relative to the first (same order as records())
 
     def __enter__(self):
         _lib.check(_lib.load().mafed_prof_begin(self.max_records), "mafed_prof_begin")
@@ -44,9 +45,10 @@ class KernelProfile:
         if self._records is None:
             torch.cuda.synchronize()
             lib = _lib.load()
-            n = lib.mafed_prof_collect(None, None, None, 0)
-            tags, work, ms = (C.c_int * n)(), (C.c_double * n)(), (C.c_float * n)()
-            lib.mafed_prof_collect(C.cast(tags, C.c_void_p), C.cast(work, C.c_void_p), C.cast(ms, C.c_void_p), n)
+            n = lib.mafed_prof_collect(None, None, None, None, 0)
+            tags, work, ms, st = (C.c_int * n)(), (C.c_double * n)(), (C.c_float * n)(), (C.c_float * n)()
+            lib.mafed_prof_collect(C.cast(tags, C.c_void_p), C.cast(work, C.c_void_p), C.cast(ms, C.c_void_p), C.cast(st, C.c_void_p), n)
+            self.starts_ms = [float(st[i]) for i in range(n)]
             names = {}
             out = []
             for i in range(n):

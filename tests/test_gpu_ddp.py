@@ -132,3 +132,55 @@ def test_ddp_step_equals_mean_of_rank_gradients(world, pipeline, mode, grad_dtyp
     else:  # bf16 buckets: every gradient element carries a 2^-9 relative rounding; AdamW's normalised update keeps it bounded by lr
         np.testing.assert_allclose(res[0][1], gns, rtol=1e-2)
         np.testing.assert_allclose(res[0][2], model.flat_params.detach().cpu().numpy(), rtol=0, atol=2.5e-3)
+
+
+def _rccl_worker(port, q, mode, grad_dtype):
+    """ONE rank on the box's one GPU over the real RCCL backend ("nccl"): the collectives the N > 1 run issues -- ReduceOp.AVG
+    all-reduce, reduce-scatter + all-gather, bf16 staging, side-stream ordering -- go through RCCL itself; with a single rank the
+    mean is the identity, so the step must equal the plain single-process step."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg = tiny_cfg("m64")
+        sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
+        tsd = R.perturb(sd, seed=22, std=5e-3)
+        out = []
+        for ddp in (True, False):
+            model, fd, tr = _make(cfg, sd, tsd, ddp, None, pipeline=True, mode=mode, grad_dtype=grad_dtype)
+            if ddp:
+                assert tr.reducer._nccl and tr.reducer._avg and tr.reducer.world == 1
+                tr.reducer.force = True
+            bs = _batches(cfg, 0)
+            gns = []
+            for i in range(4):
+                fd.mem_dataloader = [dict(bs[(i + 1) % 4])]
+                rec = tr.step(dict(bs[i]), i)
+                if rec["stepped"]:
+                    gns.append(float(rec["grad_norm"]))
+            tr.join()
+            torch.cuda.synchronize()
+            if ddp:
+                assert tr.reducer.bytes_per_step == model.flat_grads.numel() * (2 if grad_dtype is not None else 4)
+            out.append((gns, model.flat_params.detach().cpu().numpy()))
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode,grad_dtype", [("all_reduce", None), ("reduce_scatter", None), ("all_reduce", torch.bfloat16), ("reduce_scatter", torch.bfloat16)])
+def test_single_rank_rccl_collectives_are_the_identity(mode, grad_dtype):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, mode, grad_dtype))
+    p.start()
+    (g_ddp, p_ddp), (g_ref, p_ref) = q.get(timeout=400)
+    p.join(60)
+    if grad_dtype is None:
+        np.testing.assert_allclose(g_ddp, g_ref, rtol=1e-6)
+        np.testing.assert_allclose(p_ddp, p_ref, rtol=0, atol=1e-7)
+    else:
+        np.testing.assert_allclose(g_ddp, g_ref, rtol=1e-2)
+        np.testing.assert_allclose(p_ddp, p_ref, rtol=0, atol=2.5e-3)

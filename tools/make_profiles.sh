@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 500 python3 bench.py 2> $OUT/bench_stderr.log | tail -1 > $OUT/bench_line.json
 rm -rf gpurun_out/prof_kt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary > /dev/null 2>&1
 ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
 kt=$(find gpurun_out/prof_kt -name "*kernel_trace.csv" | head -1)
 python3 - "$ks" "$kt" $OUT <<'PY'
@@ -42,7 +42,7 @@ python3 tools/trace_timeline.py "$kt" 8 > $OUT/timeline.txt
 rm -rf gpurun_out/prof_kt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/prof_$c
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 bench.py --no-cpu-baseline --no-gemm-events --steps 3 --warmup 2 > /dev/null 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --steps 3 --warmup 2 > /dev/null 2>&1
 done
 python3 - $OUT <<'PY'
 import csv, glob, json, sys
@@ -66,4 +66,17 @@ json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(res)
 PY
 rm -rf gpurun_out/prof_FETCH_SIZE gpurun_out/prof_WRITE_SIZE
+# MFMA utilisation / LDS conflicts of the dominant kernel on its two biggest shapes (isolated launches; counters in their own passes)
+for shape in "0 1 9216 4096 1024" "0 0 9216 1024 4096"; do
+  tag=$(echo $shape | tr ' ' '_')
+  i=0
+  for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY" "SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"; do
+    rm -rf gpurun_out/prof_gemm_$i
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/prof_gemm_$i -- python3 tools/gemm_one.py 0 $shape 20 > /dev/null 2>&1
+    i=$((i+1))
+  done
+  mkdir -p gpurun_out/prof_gemm_all && rm -rf gpurun_out/prof_gemm_all/* && cp -r gpurun_out/prof_gemm_0 gpurun_out/prof_gemm_1 gpurun_out/prof_gemm_2 gpurun_out/prof_gemm_all/
+  python3 tools/pmc_summary.py gpurun_out/prof_gemm_all gemm_bf16 > $OUT/gemm_pmc_$tag.json
+  rm -rf gpurun_out/prof_gemm_0 gpurun_out/prof_gemm_1 gpurun_out/prof_gemm_2 gpurun_out/prof_gemm_all
+done
 cat $OUT/bench_line.json | cut -c1-400

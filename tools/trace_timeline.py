@@ -14,7 +14,7 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]))
 rows.sort()
 short = lambda n: re.sub(r"\(.*", "", n).replace("void mafed::", "").replace("mafed::", "")[:70]
-adam = [i for i, r in enumerate(rows) if "adamw_kernel<true>" in r[3] or "adamw_kernel<false>" in r[3]]
+adam = [i for i, r in enumerate(rows) if "adamw_kernel<" in r[3]]
 # a step = (end of the previous step's last adamw launch, end of this step's last adamw launch]
 ends = [rows[i][1] for i in adam]
 # group adamw launches that are close together (several per step)
