@@ -107,6 +107,19 @@ def _spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def dump_profile(directory, name, kp, rank):
+    """The raw records of one KernelProfile (what every `frac` of the line is computed from) -> CSV, so that the numbers can be
+    recomputed without re-running: achieved = sum(work) / sum(duration) per kernel tag."""
+    if not directory or rank != 0:
+        return
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, name), "w") as fp:
+        fp.write("# in-library kernel profiler (start/stop events per launch, hipExtLaunchKernelGGL); work = algorithmic flops (gemm / attn tags) or bytes\n")
+        fp.write("kernel,work,start_ms,duration_us\n")
+        for (tag, work, ms), st in zip(kp.records(), kp.starts_ms):
+            fp.write(f"{tag},{work:.6g},{st:.4f},{ms * 1e3:.3f}\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +132,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel roofline steps after the timed region")
+    ap.add_argument("--dump-profile", default=None, metavar="DIR", help="write the per-launch records behind `roofline` / `kernels` as CSV (tag, "
+                    "algorithmic work, start ms, duration us) for the timed configuration and for the single-stream repeat")
     ap.add_argument("--no-secondary", action="store_true", help="skip the blended-schedule measurement (3 CE + 1 MAFED micro-batches)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
@@ -234,6 +249,7 @@ def main():
                 tr.step(task_batch, args.warmup + args.steps + i)
             torch.cuda.synchronize()
         prof_step = kp.summary()
+        dump_profile(args.dump_profile, "kernel_profile_timed.csv", kp, rank)
         # ... and once more with the side streams switched off (dW GEMMs, teacher forward and the optimiser in line on one
         # stream): every kernel then has the chip to itself -- what a per-kernel roofline is read against
         ov = (student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer)
@@ -244,6 +260,7 @@ def main():
                 tr.step(task_batch, args.warmup + args.steps + N_PROF + i)
             torch.cuda.synchronize()
         prof_alone = kp1.summary()
+        dump_profile(args.dump_profile, "kernel_profile_no_overlap.csv", kp1, rank)
         student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer = ov
         barrier()
 
@@ -308,6 +325,10 @@ def main():
                     "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch)",
                     "mode": f"sum(2MNK) / sum(kernel execution time) over {N_PROF} steps of the timed configuration (side streams on: kernels "
                             "share the chip), start/stop events on each launch = rocprofv3 --kernel-trace durations",
+                    "records": "profiles/r02_kernel_profile_timed.csv (this command with --dump-profile; rocprofv3 --kernel-trace of the same command "
+                               "is in profiles/r02_bench_kernel_stats.csv -- its host overhead delays the student's launches by ~7 ms per step, the "
+                               "streams overlap less and every kernel looks ~20 % shorter there; the single-stream figures below agree with "
+                               "profiles/r02_bench_no_overlap_kernel_stats.csv)",
                     "launches_per_step": round(gm["launches"] / N_PROF, 1), "avg_launch_us": round(gm["avg_us"], 2),
                     "avg_gflop_per_launch": round(gm["work"] / gm["launches"] / 1e9, 3)}
             if prof_alone and "gemm_bf16" in prof_alone:

@@ -524,12 +524,12 @@ __device__ __forceinline__ float col_sum_sw(float v) {
 
 // DMA `nrows` rows (multiple of 32) of a [*, D] matrix into the swizzled image; rows >= S re-read row S-1 (finite data that
 // the masks turn into exact zeros).  1 KiB per wave instruction = 8 rows (D = 64) or 4 rows (D = 128).
-template <int D>
+template <int D, int NW = 4>
 __device__ __forceinline__ void dma_rows(char* __restrict__ img, const bf16_t* __restrict__ base, int64_t rstride, int nrows, int S, int wave,
                                          int lane) {
   constexpr int RPP = 1024 / (2 * D);
   const int npieces = nrows / RPP;
-  for (int j = wave; j < npieces; j += 4) {
+  for (int j = wave; j < npieces; j += NW) {
     int row, logical;
     if (D == 64) {
       row = j * 8 + (lane >> 3);
@@ -572,13 +572,13 @@ __device__ __forceinline__ void rot_apply(char* __restrict__ img, int it, int hc
   *p1 = pack8(o1);
   *p2 = pack8(o2);
 }
-template <int D>
+template <int D, int NT = 256>
 __device__ __forceinline__ void rot_fix_rows(char* __restrict__ img, int items, int hc, int rot, const float* __restrict__ rc,
                                              const float* __restrict__ rs, const RotPre (&pre)[2], int tid) {
 #pragma unroll
   for (int u = 0; u < 2; ++u)
-    if (tid + 256 * u < items) rot_apply<D>(img, tid + 256 * u, hc, pre[u]);
-  for (int it = tid + 512; it < items; it += 256) {
+    if (tid + NT * u < items) rot_apply<D>(img, tid + NT * u, hc, pre[u]);
+  for (int it = tid + 2 * NT; it < items; it += NT) {
     RotPre r;
     rot_pre_load(r, it, hc, rot, rc, rs);
     rot_apply<D>(img, it, hc, r);
@@ -598,15 +598,24 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 
 // slice of wave w in round t: rounds of 4 slices, direction alternating, from the heaviest slice down
 __device__ __forceinline__ int snake4(int w, int t) { return t * 4 + ((t & 1) ? 3 - w : w); }
+template <int NW>
+__device__ __forceinline__ int snake(int w, int t) { return t * NW + ((t & 1) ? NW - 1 - w : w); }
 
 #define MAFED_LOG2E 1.4426950408889634f
 #define MAFED_LN2 0.6931471805599453f
 
+// (D = 64: EIGHT waves per block.  The slice loop is a dependency chain -- QK^T MFMAs, the four-lane max, exponentials, PV MFMAs --
+// with ~100 VALU instructions per 64-key tile; at 126 VGPRs four waves fit on a SIMD, and twice the waves over the same resident
+// K / V image halve each wave's chain and hide twice the latency.  The backward kernels need > 200 VGPRs and stay at four.)
+template <int D>
+constexpr int attn_fwd_waves() { return D == 64 ? 8 : 4; }
+
 template <int D, bool CAUSAL = true>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
+__global__ __launch_bounds__(attn_fwd_waves<D>() * 64, (D == 64 ? 2 : 1) * attn_fwd_waves<D>() / 4) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, AttnShape sh, const float* __restrict__ rc,
                                                            const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                            bf16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NW = attn_fwd_waves<D>(), NTH = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
@@ -625,23 +634,23 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
   if (tid == 0) out[((int64_t)b * S) * H * D + (int64_t)h * D] = 0;
   return;
 #endif
-  dma_rows<D>(kimg, kb, rstride, nrows, S, wave, lane);
+  dma_rows<D, NW>(kimg, kb, rstride, nrows, S, wave, lane);
 #if !defined(MAFED_ATTN_ABL) || MAFED_ATTN_ABL != 4
-  dma_rows<D>(vimg, vb, rstride, nrows, S, wave, lane);
+  dma_rows<D, NW>(vimg, vb, rstride, nrows, S, wave, lane);
 #endif
   RotPre pre[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
-    if (tid + 256 * u < items) rot_pre_load(pre[u], tid + 256 * u, hc, rot, rc, rs);
-  for (int k = tid; k < nrows; k += 256) kbias[k] = key_ok(am, b, k, P, T, S) ? 0.f : -INFINITY;
+    if (tid + NTH * u < items) rot_pre_load(pre[u], tid + NTH * u, hc, rot, rc, rs);
+  for (int k = tid; k < nrows; k += NTH) kbias[k] = key_ok(am, b, k, P, T, S) ? 0.f : -INFINITY;
   ColRaw<D> qraw;
   {
-    const int s0 = nslices - 1 - snake4(wave, 0);
+    const int s0 = nslices - 1 - snake<NW>(wave, 0);
     if (s0 >= 0) col_raw_issue<D, true>(qraw, qb, rstride, s0 * 16, S, rot, rc, rs, lane);
   }
   wait_vm0();
   __syncthreads();
-  rot_fix_rows<D>(kimg, items, hc, rot, rc, rs, pre, tid);
+  rot_fix_rows<D, NTH>(kimg, items, hc, rot, rc, rs, pre, tid);
   __syncthreads();
 #if defined(MAFED_ATTN_ABL) && (MAFED_ATTN_ABL == 1 || MAFED_ATTN_ABL == 4)
   if (tid < 64) out[((int64_t)b * S + tid) * H * D + (int64_t)h * D] = *reinterpret_cast<const bf16_t*>(kimg + tid * 1024) + *reinterpret_cast<const bf16_t*>(vimg + tid * 1024);
@@ -650,14 +659,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
   const int g = lane >> 4;
   const float scale2 = rsqrtf((float)D) * MAFED_LOG2E;
   for (int t = 0;; ++t) {
-    const int slice = nslices - 1 - snake4(wave, t);
+    const int slice = nslices - 1 - snake<NW>(wave, t);
     if (slice < 0) break;
     const int q0 = slice * 16;
     const int myq = q0 + (lane & 15);
     bf16x8 qf[D / 32];
     col_raw_finish<D, true>(qf, qraw, q0, S, rot, lane);
     {
-      const int nxt = nslices - 1 - snake4(wave, t + 1);
+      const int nxt = nslices - 1 - snake<NW>(wave, t + 1);
       if (nxt >= 0) col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
     }
     f32x4 o[D / 16];
@@ -755,13 +764,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_res_kernel(cons
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+template <int D, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (D == 64 ? 2 : 1) * NW / 4) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse, AttnShape sh,
                                                               const float* __restrict__ rc, const float* __restrict__ rs,
                                                               const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
                                                               float* __restrict__ delta, float* __restrict__ bsum) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NTH = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
@@ -782,17 +792,20 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_res_kernel(c
   const float* Lrow = lse + ((int64_t)b * H + h) * S;
   const int nslices = (S + 15) / 16;
   const int hc = rot >> 4, items = S * hc;
-  dma_rows<D>(kimg, kb, rstride, nrows, S, wave, lane);
-  dma_rows<D>(vimg, vb, rstride, nrows, S, wave, lane);
+  dma_rows<D, NW>(kimg, kb, rstride, nrows, S, wave, lane);
+  dma_rows<D, NW>(vimg, vb, rstride, nrows, S, wave, lane);
   RotPre pre[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
-    if (tid + 256 * u < items) rot_pre_load(pre[u], tid + 256 * u, hc, rot, rc, rs);
-  for (int k = tid; k < nrows; k += 256) kbias[k] = key_ok(am, b, k, P, T, S) ? 0.f : -INFINITY;
+    if (tid + NTH * u < items) rot_pre_load(pre[u], tid + NTH * u, hc, rot, rc, rs);
+  for (int k = tid; k < nrows; k += NTH) kbias[k] = key_ok(am, b, k, P, T, S) ? 0.f : -INFINITY;
+  // NW = 4: the next slice's q / dO / O rows are requested a slice ahead (84 VGPRs of raw data).  NW = 8: four waves per SIMD hide
+  // that latency themselves, and the registers are what lets them be resident
+  constexpr bool PREFETCH = NW == 4;
   ColRaw<D> qraw, doraw, oraw;
   float Lnext = 0.f;
-  {
-    const int s0 = nslices - 1 - snake4(wave, 0);
+  if (PREFETCH) {
+    const int s0 = nslices - 1 - snake<NW>(wave, 0);
     if (s0 >= 0) {
       col_raw_issue<D, true>(qraw, qb, rstride, s0 * 16, S, rot, rc, rs, lane);
       col_raw_issue<D, false>(doraw, dob, ostride, s0 * 16, S, 0, rc, rs, lane);
@@ -803,16 +816,22 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_res_kernel(c
   }
   wait_vm0();
   __syncthreads();
-  rot_fix_rows<D>(kimg, items, hc, rot, rc, rs, pre, tid);
+  rot_fix_rows<D, NTH>(kimg, items, hc, rot, rc, rs, pre, tid);
   __syncthreads();
   const int g = lane >> 4;
   const float scale = rsqrtf((float)D);
   const float scale2 = scale * MAFED_LOG2E;
   for (int t = 0;; ++t) {
-    const int slice = nslices - 1 - snake4(wave, t);
+    const int slice = nslices - 1 - snake<NW>(wave, t);
     if (slice < 0) break;
     const int q0 = slice * 16;
     const int myq = q0 + (lane & 15);
+    if (!PREFETCH) {
+      col_raw_issue<D, true>(qraw, qb, rstride, q0, S, rot, rc, rs, lane);
+      col_raw_issue<D, false>(doraw, dob, ostride, q0, S, 0, rc, rs, lane);
+      col_raw_issue<D, false>(oraw, ob, ostride, q0, S, 0, rc, rs, lane);
+      Lnext = myq < S ? Lrow[myq] : 0.f;
+    }
     bf16x8 qf[D / 32], dof[D / 32];
     col_raw_finish<D, true>(qf, qraw, q0, S, rot, lane);
     col_raw_finish<D, false>(dof, doraw, q0, S, 0, lane);
@@ -821,8 +840,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_res_kernel(c
     {
       bf16x8 of[D / 32];
       col_raw_finish<D, false>(of, oraw, q0, S, 0, lane);
-      const int nxt = nslices - 1 - snake4(wave, t + 1);
-      if (nxt >= 0) {
+      const int nxt = nslices - 1 - snake<NW>(wave, t + 1);
+      if (PREFETCH && nxt >= 0) {
         col_raw_issue<D, true>(qraw, qb, rstride, nxt * 16, S, rot, rc, rs, lane);
         col_raw_issue<D, false>(doraw, dob, ostride, nxt * 16, S, 0, rc, rs, lane);
         col_raw_issue<D, false>(oraw, ob, ostride, nxt * 16, S, 0, rc, rs, lane);
@@ -903,13 +922,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_res_kernel(c
 // dK / dV: Q (rotated) and dO of the head are resident, with the rows' log2-domain LSE and delta beside them; each wave
 // owns 16-key slices, heaviest (lowest keys) first
 // (two waves per SIMD at D = 64 -- the LDS footprint allows two blocks per CU, so the register budget is capped to match)
-template <int D>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+template <int D, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (D == 64 ? 2 : 1) * NW / 4) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta, AttnShape sh,
                                                                const float* __restrict__ rc, const float* __restrict__ rs,
                                                                const int64_t* __restrict__ am, bf16_t* __restrict__ dqkv,
                                                                float* __restrict__ bsum) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NTH = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, H = sh.H, rot = sh.rot, P = sh.P, T = sh.T;
@@ -931,19 +951,19 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
   const float* Drow = delta + ((int64_t)b * H + h) * S;
   const int nslices = (S + 15) / 16;
   const int hc = rot >> 4, items = S * hc;
-  dma_rows<D>(qimg, qb, rstride, nrows, S, wave, lane);
-  dma_rows<D>(doimg, dob, ostride, nrows, S, wave, lane);
+  dma_rows<D, NW>(qimg, qb, rstride, nrows, S, wave, lane);
+  dma_rows<D, NW>(doimg, dob, ostride, nrows, S, wave, lane);
   RotPre pre[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
-    if (tid + 256 * u < items) rot_pre_load(pre[u], tid + 256 * u, hc, rot, rc, rs);
-  for (int q = tid; q < nrows; q += 256) {
+    if (tid + NTH * u < items) rot_pre_load(pre[u], tid + NTH * u, hc, rot, rc, rs);
+  for (int q = tid; q < nrows; q += NTH) {
     L2s[q] = q < S ? Lrow[q] * MAFED_LOG2E : INFINITY;  // rows past S: exp2(x - inf) = 0
     Ds[q] = q < S ? Drow[q] : 0.f;
   }
   ColRaw<D> kraw, vraw;
   {
-    const int s0 = snake4(wave, 0);
+    const int s0 = snake<NW>(wave, 0);
     if (s0 < nslices) {
       col_raw_issue<D, true>(kraw, kb, rstride, s0 * 16, S, rot, rc, rs, lane);
       col_raw_issue<D, false>(vraw, vb, rstride, s0 * 16, S, 0, rc, rs, lane);
@@ -951,14 +971,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
   }
   wait_vm0();
   __syncthreads();
-  rot_fix_rows<D>(qimg, items, hc, rot, rc, rs, pre, tid);
+  rot_fix_rows<D, NTH>(qimg, items, hc, rot, rc, rs, pre, tid);
   __syncthreads();
   const int g = lane >> 4;
   const float scale = rsqrtf((float)D);
   const float scale2 = scale * MAFED_LOG2E;
   const int nqt = (nrows + 63) / 64;
   for (int t = 0;; ++t) {
-    const int slice = snake4(wave, t);
+    const int slice = snake<NW>(wave, t);
     if (slice >= nslices) break;
     const int k0 = slice * 16;
     const int mykey = k0 + (lane & 15);
@@ -967,7 +987,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_res_kernel(
     col_raw_finish<D, true>(kf, kraw, k0, S, rot, lane);
     col_raw_finish<D, false>(vf, vraw, k0, S, 0, lane);
     {
-      const int nxt = snake4(wave, t + 1);
+      const int nxt = snake<NW>(wave, t + 1);
       if (nxt < nslices) {
         col_raw_issue<D, true>(kraw, kb, rstride, nxt * 16, S, rot, rc, rs, lane);
         col_raw_issue<D, false>(vraw, vb, rstride, nxt * 16, S, 0, rc, rs, lane);
@@ -1080,7 +1100,7 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
                          hipStream_t st) {
   size_t bytes;
   if (g_attn_variant != 1 && attn_resident_fits(sh, &bytes)) {
-    dim3 grid(sh.H, sh.B), block(256);
+    dim3 grid(sh.H, sh.B), block(attn_fwd_waves<64>() * 64);
     if (!sh.causal) {
       if (sh.D != 64) { set_error("attn_fwd (bidirectional, bf16): head_dim %d has no MFMA kernel (CLIP towers use 64)", sh.D); return MAFED_EINVAL; }
       set_lds_attr(attn_fwd_res_kernel<64, false>, bytes);
@@ -1093,7 +1113,7 @@ int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, 
       launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_res_kernel<64>, grid, block, bytes, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
     } else {
       set_lds_attr(attn_fwd_res_kernel<128>, bytes);
-      launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_res_kernel<128>, grid, block, bytes, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
+      launch(K_ATTN_FWD, attn_fwd_flops(sh), attn_fwd_res_kernel<128>, grid, dim3(attn_fwd_waves<128>() * 64), bytes, st, (const bf16_t*)qkv, sh, rc, rs, am, (bf16_t*)out, lse);
     }
     return MAFED_OK;
   }
@@ -1153,5 +1173,6 @@ int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, con
 }
 
 void attn_mfma_set_variant(int v) { g_attn_variant = v; }
+
 
 }  // namespace mafed

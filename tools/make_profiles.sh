@@ -9,7 +9,7 @@ set -e
 OUT=gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 500 python3 bench.py 2> $OUT/bench_stderr.log | tail -1 > $OUT/bench_line.json
+timeout -k 10 500 python3 bench.py --dump-profile $OUT 2> $OUT/bench_stderr.log | tail -1 > $OUT/bench_line.json
 rm -rf gpurun_out/prof_kt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary > /dev/null 2>&1
 ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
@@ -40,6 +40,21 @@ with open(out + "/bench_kernel_by_shape.csv", "w") as g:
 PY
 python3 tools/trace_timeline.py "$kt" 8 > $OUT/timeline.txt
 rm -rf gpurun_out/prof_kt
+# the same with every kernel alone on the chip (--no-overlap: one stream): what the per-kernel `*_no_overlap` figures of the line are checked against
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-overlap --no-pipeline-optimizer > /dev/null 2>&1
+ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
+python3 - "$ks" $OUT <<'PY'
+import csv, re, sys
+ks, out = sys.argv[1:3]
+short = lambda n: re.sub(r"\(.*", "", n).replace("void mafed::", "").replace("mafed::", "")
+with open(ks) as f, open(out + "/bench_no_overlap_kernel_stats.csv", "w") as g:
+    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-overlap --no-pipeline-optimizer   (1x MI355X; one stream)\n")
+    g.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+    for row in csv.DictReader(f):
+        g.write('"%s",%s,%s,%d,%s,%s,%s\n' % (short(row["Name"]), row["Calls"], row["TotalDurationNs"], float(row["AverageNs"]), row["Percentage"], row["MinNs"], row["MaxNs"]))
+PY
+rm -rf gpurun_out/prof_kt
+python3 tools/step_timeline.py > $OUT/step_timeline_inlib.txt 2>/dev/null || true
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/prof_$c
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --steps 3 --warmup 2 > /dev/null 2>&1
