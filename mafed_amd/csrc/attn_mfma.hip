@@ -658,6 +658,7 @@ __global__ __launch_bounds__(attn_fwd_waves<D>() * 64, (D == 64 ? 2 : 1) * attn_
 #endif
   const int g = lane >> 4;
   const float scale2 = rsqrtf((float)D) * MAFED_LOG2E;
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
   for (int t = 0;; ++t) {
     const int slice = nslices - 1 - snake<NW>(wave, t);
     if (slice < 0) break;
@@ -672,7 +673,11 @@ __global__ __launch_bounds__(attn_fwd_waves<D>() * 64, (D == 64 ? 2 : 1) * attn_
     f32x4 o[D / 16];
 #pragma unroll
     for (int i = 0; i < D / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY;
+    // row sums of p through the matrix pipe: a ones[16 x 32] A operand makes every accumulator row the column sum of the bf16 p tile
+    // the PV product consumes (numerator and denominator see the same rounded probabilities); 2 MFMAs per tile on the idle pipe
+    // instead of 17 VALU adds in the VALU-bound loop, and no cross-lane reduction at the end
+    f32x4 lsum = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int last_kt = CAUSAL ? (q0 + 15) / 64 : (S - 1) / 64;  // bidirectional (CLIP tower): every slice sees every key tile
     // one 64-key tile; MASK = false for tiles that lie wholly below the diagonal and wholly inside the image keys (most of
     // them): no bias read, no compares.  nj = 16-key sub-tiles with a key <= q0 + 15.
@@ -723,25 +728,21 @@ __global__ __launch_bounds__(attn_fwd_waves<D>() * 64, (D == 64 ? 2 : 1) * attn_
         const float mn = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
-        l *= alpha;
+        lsum *= alpha;
 #pragma unroll
         for (int i = 0; i < D / 16; ++i) o[i] *= alpha;
       }
-      float ps = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(MASK ? s[j][r] - m : fmaf(s[j][r], scale2, -m));
-          s[j][r] = pv;
-          ps += pv;
-        }
-      l += ps;
+        for (int r = 0; r < 4; ++r) s[j][r] = __builtin_amdgcn_exp2f(MASK ? s[j][r] - m : fmaf(s[j][r], scale2, -m));
       const bf16x8 p0 = pack_acc(s[0], s[1]);
+      lsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, lsum, 0, 0, 0);
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2, lane), p0, o[dt], 0, 0, 0);
       if (!MASK || nj > 2) {
         const bf16x8 p1 = pack_acc(s[2], s[3]);
+        lsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, lsum, 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(vimg, dt, kt * 2 + 1, lane), p1, o[dt], 0, 0, 0);
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(attn_fwd_waves<D>() * 64, (D == 64 ? 2 : 1) * attn_
     const int klast = CAUSAL ? q0 + 15 : S - 1;  // last key any row of the slice may attend to
     for (int kt = 0; kt < kt_plain; ++kt) tile(kt, 4, std::false_type{});
     for (int kt = kt_plain; kt <= last_kt; ++kt) tile(kt, kt == last_kt ? ((klast - kt * 64) >> 4) + 1 : 4, std::true_type{});
-    l = col_sum_sw(l);
+    const float l = lsum[0];
     if (myq < S) {
       const float inv = 1.0f / l;
       bf16_t* op = out + ((int64_t)b * S + myq) * H * D + (int64_t)h * D;

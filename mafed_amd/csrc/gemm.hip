@@ -421,7 +421,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
         for (int i = 0; i < 8; ++i) cs[i] += v[i];
       }
     }
-    if (epi.colsum) colsum_flush<8>(cs, epi.colsum, n0 + wn * 64, lane);
+    if (epi.colsum) colsum_flush_block<8, TN>(cs, reinterpret_cast<float*>(smem), epi.colsum, n0, wn * 64, lane, tid);
   } else if constexpr (MT == 6 && NT == 4 && STAGE * 2 >= NW * 12288) {
     // 96 x 64 wave tile (192 x 128 block): two passes of 3 row tiles through a wave-private 48 x 64 fp32 region
     __syncthreads();
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (epi.colsum) colsum_flush<8>(cs, epi.colsum, n0 + wn * 64, lane);
+    if (epi.colsum) colsum_flush_block<8, TN>(cs, reinterpret_cast<float*>(smem), epi.colsum, n0, wn * 64, lane, tid);
   } else if constexpr (MT == 9 && NT == 4 && STAGE * 2 >= NW * 12288) {
     // 144 x 64 wave tile (288 x 256 block): three passes of 3 row tiles through a wave-private 48 x 64 fp32 region
     __syncthreads();
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (epi.colsum) colsum_flush<8>(cs, epi.colsum, n0 + wn * 64, lane);
+    if (epi.colsum) colsum_flush_block<8, TN>(cs, reinterpret_cast<float*>(smem), epi.colsum, n0, wn * 64, lane, tid);
   } else if constexpr (MT == 9 && NT == 2 && WM == 1 && STAGE * 2 >= NW * 10240) {
     // 144 x 32 wave tile: same idea in two passes (row tiles 0-4, then 5-8) through a wave-private 80 x 32 fp32 region
     __syncthreads();
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (epi.colsum) colsum_flush<4>(cs, epi.colsum, n0 + wn * 32, lane);
+    if (epi.colsum) colsum_flush_block<4, TN>(cs, reinterpret_cast<float*>(smem), epi.colsum, n0, wn * 32, lane, tid);
   } else {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -143,6 +143,32 @@ __device__ __forceinline__ void colsum_flush(float (&cs)[8], float* __restrict__
   }
 }
 
+// Block-level form: the waves of a block first fold their sums in LDS (`lds_sum`: TN floats at the start of the block's LDS), then the block issues
+// TN / 64 full-width atomic instructions (256 contiguous bytes each: the full-rate shape of MI355X_MICROARCH "Global float atomics")
+// instead of 8 (or 4) eight-lane instructions per wave -- the cost of a float atomic is per INSTRUCTION (~50 ns per CU), and the
+// per-wave form cost the GELU' GEMM of the step 18 us of its 132.  `wcol0` = first tile column of this wave.  Contains barriers:
+// every thread of the block calls it.
+template <int JL, int TN>
+__device__ __forceinline__ void colsum_flush_block(float (&cs)[8], float* __restrict__ lds_sum, float* __restrict__ colsum, int64_t n0, int wcol0,
+                                                   int lane, int tid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = cs[i];
+#pragma unroll
+    for (int o = JL; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    cs[i] = v;
+  }
+  __syncthreads();  // every wave is done with its staging region: `lds_sum` re-uses the start of that memory
+  if (tid < TN) lds_sum[tid] = 0.f;
+  __syncthreads();
+  if (lane < JL) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(lds_sum + wcol0 + 8 * lane + i, cs[i]);  // ds_add_f32
+  }
+  __syncthreads();
+  if (tid < TN) atomicAdd(colsum + n0 + tid, lds_sum[tid]);
+}
+
 // decode-path product (gemm_skinny.hip)
 bool gemm_skinny_ok(int transA, int transB, int64_t M, int64_t N, int64_t K, float beta, const void* colsum);
 int gemm_skinny_launch(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, mafed_dtype c_dtype,
