@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--dump-profile", default=None, metavar="DIR", help="write the per-launch records behind `roofline` / `kernels` as CSV (tag, "
                     "algorithmic work, start ms, duration us) for the timed configuration and for the single-stream repeat")
     ap.add_argument("--no-secondary", action="store_true", help="skip the blended-schedule measurement (3 CE + 1 MAFED micro-batches)")
+    ap.add_argument("--no-image-leg", action="store_true", help="skip the image-input measurement (CLIP-ViT-L/14 tower in front of the step)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
@@ -304,6 +305,63 @@ def main():
                      "mfma_frac_whole_step": round(fl2 * n_opt / dt2 / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(rec2["loss"]), 5)}
         log(f"secondary: {n_opt} optimiser steps in {dt2 * 1e3:.1f} ms")
 
+    # third leg: the same all-distill step fed with IMAGES (pixel_values [B,3,224,224] -> native frozen CLIP-ViT-L/14 tower -> step), the
+    # data path of upstream's training loop; the tower runs once per step (upstream: twice, distillation.py:91,222).  Random tower weights.
+    image_leg = None
+    if not args.no_image_leg and cfg.vision_hidden_size == 1024 and P == 256:
+        from mafed_amd.vision import ClipVisionConfig, ClipVisionTower
+        tr.join()
+        student.zero_grad()
+        tower = ClipVisionTower(ClipVisionConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                                                 image_size=224, patch_size=14), compute_dtype=cd, device=dev)
+        gt = torch.Generator(device=dev).manual_seed(4321)
+        with torch.no_grad():
+            for prm in tower.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=gt, device=dev) * 0.02)
+        tower._derived = None
+        student.vision_encoder = tower
+        fd.past_model.vision_encoder = tower
+        img_batches = []
+        for j in range(2):
+            sl = slice(j * B, (j + 1) * B)
+            img_batches.append({"input_ids": ids[sl].to(dev), "attention_mask": torch.ones(B, T, dtype=torch.int64, device=dev), "labels": labels[sl].to(dev),
+                                "pixel_values": torch.randn(B, 3, 224, 224, generator=gt, device=dev).to(cd)})
+
+        class _Cycle:   # memory loader handing out image batches (fresh dict per draw: replay() adds keys to it)
+            def __init__(self):
+                self.i = 0
+            def __iter__(self):
+                return self
+            def __next__(self):
+                self.i += 1
+                return dict(img_batches[self.i % 2])
+        fd.mem_dataloader = _Cycle()
+        fd.batch_size = B
+        tr3 = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
+                      bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt)
+        n3 = max(5, args.steps // 2)
+        for i in range(3):
+            tr3.step(task_batch, i)
+        torch.cuda.synchronize()
+        barrier()
+        t3 = time.perf_counter()
+        for i in range(n3):
+            rec3 = tr3.step(task_batch, 3 + i)
+        torch.cuda.synchronize()
+        barrier()
+        dt3 = time.perf_counter() - t3
+        t3t = torch.tensor([dt3], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t3t, op=dist.ReduceOp.MAX)
+        dt3 = float(t3t.item())
+        tr3.join()
+        image_leg = {"metric": "train samples/s, the headline step fed with images: pixel_values [B,3,224,224] bf16 -> frozen CLIP-ViT-L/14 tower "
+                               "(23 of 24 layers, 257 tokens, once per step for student + teacher) -> MAFED step",
+                     "value": round(n3 * B * world / dt3, 3), "unit": "samples/s", "steps": n3, "ms_per_step": round(dt3 / n3 * 1e3, 3),
+                     "final_loss": round(float(rec3["loss"]), 5)}
+        assert image_leg["final_loss"] == image_leg["final_loss"], "NaN loss in the image-input leg"
+        log(f"image-input leg: {n3} steps in {dt3 * 1e3:.1f} ms")
+
     if rank == 0:
         samples = args.steps * B * world
         value = samples / dt
@@ -371,6 +429,8 @@ def main():
             out["kernels"] = kernels
         if secondary:
             out["secondary"] = secondary
+        if image_leg:
+            out["image_input"] = image_leg
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model, P, T)

@@ -232,8 +232,11 @@ extern "C" int mafed_gemm_set_trace(void* buf) {
 #endif
 
 // ABL (tuning only): 0 = real kernel; 1 = no DMA inside the loop; 2 = no MFMAs (fragments kept live); 3 = no fragment reads
-template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
+// KG (1 or 2): K groups inside the block.  With KG = 2 a second set of WM x WN waves works on the other half of the
+// block's K range through its own pair of LDS stages and hands its accumulators over through LDS at the end: two waves
+// per SIMD on GEMMs whose output has only as many tiles as the chip has CUs (dW += dY^T.X), without split-K atomics.
+template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0, int KG = 1>
+__global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
                                                                        int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                        CT* __restrict__ C, GemmEpi epi, int tiles_n, int nwg) {
   // block tile TM x TN x 64; WM x WN waves, each owning (MT*16) x (NT*16) outputs = MT x NT accumulators of 16x16.
@@ -246,9 +249,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
   static_assert(TM % 8 == 0 && TN % 8 == 0, "tile must be a multiple of the 8-row DMA piece");
   static_assert(!A_KS || TM == 64 || TM % 128 == 0, "the [k][row] image needs 64 or 128-row multiples");
   static_assert(!B_KS || TN == 64 || TN % 128 == 0, "the [k][row] image needs 64 or 128-row multiples");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(KG == 1 || (KG == 2 && MT == 4 && NT == 4), "K groups: 64 x 64 wave tiles only");
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 1 ? 0 : wave_all / NW, wave = KG == 1 ? wave_all : wave_all % NW;
+  char* const smem = smem_all + kg * (2 * STAGE);   // this K group's two operand stages
   const int wm = wave / WN, wn = wave % WN;
   int bid = blockIdx.x;
   {
@@ -324,8 +330,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
 
   // split-K (gridDim.y > 1, accumulate-only fp32 outputs): this block owns K-tiles [kt0, kt0 + nkt)
   const int nkt_all = (int)(K / BK);
-  const int kt0 = (int)((int64_t)nkt_all * blockIdx.y / gridDim.y);
-  const int nkt = (int)((int64_t)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
+  int kt0 = (int)((int64_t)nkt_all * blockIdx.y / gridDim.y);
+  int nkt = (int)((int64_t)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
+  if (KG > 1) {  // the dispatcher only picks KG = 2 when every block's range halves evenly (same barrier count in both groups)
+    nkt /= KG;
+    kt0 += kg * nkt;
+  }
 #pragma unroll
   for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] += kt0 * a_step;
 #pragma unroll
@@ -386,6 +396,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
     // 32-byte row segments); re-read as 8 consecutive columns per lane so that C / aux / residual traffic moves in
     // 128-256 contiguous bytes per row.  Wave-private 64x64 fp32 region, float4 slot XOR (row & 15): conflict-free both ways.
     __syncthreads();  // every wave is done with the operand stages
+    if constexpr (KG > 1) {
+      // group 1 hands its partial sums to the same-numbered wave of group 0 (wave-private 16 KiB slot in group 0's stages,
+      // one f32x4 per lane and accumulator: conflict-free) and leaves; from here on group 0's LDS use is wave-private
+      f32x4* xch = reinterpret_cast<f32x4*>(smem_all) + wave * 1024;
+      if (kg == 1) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) xch[(nt * 4 + mt) * 64 + lane] = acc[nt][mt];
+      }
+      __syncthreads();
+      if (kg == 1) return;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] += xch[(nt * 4 + mt) * 64 + lane];
+      __builtin_amdgcn_wave_barrier();
+    }
     float* reg = reinterpret_cast<float*>(smem) + wave * 4096;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -540,20 +568,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_glds_kernel(int64_t M,
 static int g_gemm_group_m = 4;  // row-tiles per L2 patch of the grouped tile order (tuning: variant 300 + g)
 static int g_gemm_nsplit = 1;  // set by the dispatcher for the next launch_bf16_glds<2,2,4,4,...> (split-K, accumulate-only)
 
-template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0>
+template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0, int KG = 1>
 static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                             const GemmEpi& epi, hipStream_t st) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, LDS = 2 * (TM + TN) * 128;
+  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, LDS = KG * 2 * (TM + TN) * 128;
   const int64_t tm = M / TM, tn = N / TN, nwg = tm * tn;
   if (nwg > 0x7fffffff) { set_error("gemm: grid too large"); return MAFED_EINVAL; }
-  auto kfn = gemm_bf16_glds_kernel<WM, WN, MT, NT, A_KS, B_KS, CT, ABL>;
+  auto kfn = gemm_bf16_glds_kernel<WM, WN, MT, NT, A_KS, B_KS, CT, ABL, KG>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int nsplit = (MT == 4 && NT == 4 && WM == 2 && WN == 2) ? g_gemm_nsplit : 1;
-  launch(K_GEMM_BF16, 2.0 * M * N * K, kfn, dim3((unsigned)nwg, (unsigned)nsplit), dim3(WM * WN * 64), LDS, st, M, N, K, (const bf16_t*)A, lda,
+  if (KG > 1 && ((K / BK) % (nsplit * KG) != 0 || epi.colsum)) { set_error("gemm: K groups need an even K-tile count per block and no fused column sums"); return MAFED_EINVAL; }
+  launch(K_GEMM_BF16, 2.0 * M * N * K, kfn, dim3((unsigned)nwg, (unsigned)nsplit), dim3(WM * WN * KG * 64), LDS, st, M, N, K, (const bf16_t*)A, lda,
          (const bf16_t*)B, ldb, (CT*)C, epi, (int)tn | (g_gemm_group_m << 20), (int)nwg);
   return MAFED_OK;
 }
@@ -834,6 +863,7 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
     case 13: if constexpr (!A_KS) return launch_bf16_glds<1, 8, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x256, 8 waves of 144x32
     case 16: if constexpr (!A_KS) return launch_bf16_glds<2, 4, 9, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 288x256, 8 waves of 144x64 (136 KiB, 1 block / CU)
     case 17: if constexpr (!A_KS) return launch_bf16_glds<2, 2, 6, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 192x128, 4 waves of 96x64 (80 KiB: 2 blocks / CU)
+    case 18: if constexpr (sizeof(CT) == 4) return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 0, 2>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 128x128, two K groups of 4 waves (128 KiB, 1 block / CU)
     case 14: return launch_bf16_glds<2, 2, 4, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x64, 4 waves of 64x32 (48 KiB: 3 blocks / CU)
     case 15: return launch_bf16_glds<2, 2, 2, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 64x128
     case 21: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 1>(M, N, K, A, lda, B, ldb, C, epi, st);  // ablations (timing only)
@@ -875,8 +905,10 @@ using namespace mafed;
 // test / tuning hook: 0 = automatic, 1 = force the register-staged kernel
 static int g_gemm_variant = 0;
 static int g_gemm_big = 0;    // 288x256 configuration in automatic mode (200 = off, 201 = on): faster alone, slower beside the side streams
+static int g_gemm_kgroups = 0;  // two K groups per block for the one-tile-per-CU weight gradients (400 = off, 401 = on): 9 % faster alone, 2.5 % slower step (no dX block fits beside a 128 KiB block)
 static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
 extern "C" int mafed_gemm_set_variant(int v) {
+  if (v >= 400) { g_gemm_kgroups = v - 400; return MAFED_OK; }
   if (v >= 300) { g_gemm_group_m = v - 300 > 0 ? v - 300 : 1; return MAFED_OK; }
   if (v >= 200) { g_gemm_big = v - 200; return MAFED_OK; }
   if (v >= 100) { g_gemm_split = v - 100; return MAFED_OK; }  // 100 = automatic split-K, 101 = off, 100 + n = force n
@@ -957,6 +989,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
       else if (want == 17 && (M % 192 == 0) && (N % 128 == 0) && !a_ks) cfg = 17;
       else if (want == 14 && (M % 128 == 0) && (N % 64 == 0)) cfg = 14;
       else if (want == 15 && (M % 64 == 0) && (N % 128 == 0)) cfg = 15;
+      else if (want == 18 && ok128 && c_dtype == MAFED_F32 && !colsum && (K / 64) % 2 == 0) cfg = 18;
       else if (((want == 0 || want == 3 || want == 6 || want == 7 || want == 9 || want == 10 || (want >= 21 && want <= 26)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
       else if (ok128) cfg = 0;
     } else {
@@ -977,11 +1010,17 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     }
   }
   g_gemm_nsplit = 1;
-  if (cfg == 0 && c_dtype == MAFED_F32 && beta == 1.0f && !bias && epilogue == MAFED_EPI_NONE && !res1 && !res2 && g_gemm_split != 1) {
+  // weight gradients with one 128 x 128 tile per CU (4096 x 1024 and 1024 x 4096 at K = 9216): two K groups per block give
+  // every SIMD a second wave without split-K atomics (isolated 88-94 vs 99-102 us)
+  if (cfg == 0 && g_gemm_variant == 0 && g_gemm_kgroups && c_dtype == MAFED_F32 && beta == 1.0f && !bias && epilogue == MAFED_EPI_NONE && !res1 &&
+      !res2 && !colsum && (M / 128) * (N / 128) >= 225 && (M / 128) * (N / 128) <= 256 && (K / 64) % 2 == 0 && K >= 2048)
+    cfg = 18;
+  if ((cfg == 0 || cfg == 18) && c_dtype == MAFED_F32 && beta == 1.0f && !bias && epilogue == MAFED_EPI_NONE && !res1 && !res2 && g_gemm_split != 1) {
     // weight-gradient GEMMs (dW += dY^T.X): few output tiles, very long K.  Split K so that the grid fills the chip.
     const int64_t tiles = (M / 128) * (N / 128), nkt = K / 64;
     int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? (nkt >= 512 ? 8 : 4) : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
     while (ns > 1 && nkt / ns < 8) ns >>= 1;
+    if (cfg == 18) while (ns > 1 && nkt % (2 * ns) != 0) ns >>= 1;
     g_gemm_nsplit = ns;
   }
   if (cfg >= 0) {

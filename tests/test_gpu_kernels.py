@@ -64,7 +64,7 @@ GEMM_SHAPES = [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024
 GEMM_CASES = [(v, s) for v in (0, 1, 21, 27) for s in GEMM_SHAPES] + [
     (11, (512, 768, 320)), (12, (512, 768, 320)), (13, (384, 640, 192)), (14, (512, 768, 320)), (15, (512, 768, 320)), (16, (384, 640, 192)),
     (17, (384, 640, 192)), (18, (512, 768, 320)), (22, (576, 384, 128)), (23, (576, 768, 256)), (24, (384, 640, 192)), (25, (384, 640, 192)),
-    (26, (576, 768, 256))]
+    (26, (576, 768, 256)), (28, (512, 768, 384)), (28, (256, 128, 1152))]
 
 
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False), (True, True)])
@@ -152,9 +152,11 @@ def test_gemm_skinny_decode_shapes(M, N, K):
     assert float(cache[:, 0, :].abs().max()) == 0.0 and float(cache[:, 2, :].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kgroups", [False, True])
 @pytest.mark.parametrize("split", [100, 101, 102, 104, 108])
-def test_gemm_split_k_accumulate(split):
-    """dW += dY^T.X with K split over blockIdx.y and fp32 atomics into the running gradient (100 = automatic choice)."""
+def test_gemm_split_k_accumulate(split, kgroups):
+    """dW += dY^T.X with K split over blockIdx.y and fp32 atomics into the running gradient (100 = automatic choice);
+    ``kgroups``: the 8-wave tile whose two wave groups each take half of the block's K range (hand-over through LDS)."""
     ops = _ops()
     from mafed_amd import _lib
     g = torch.Generator().manual_seed(9)
@@ -164,10 +166,13 @@ def test_gemm_split_k_accumulate(split):
     c0 = _int_mat((M, N), g, -50, 50)
     out = c0.clone().to(DEV)
     _lib.load().mafed_gemm_set_variant(split)
+    if kgroups:
+        _lib.load().mafed_gemm_set_variant(28)
     try:
         ops.gemm(A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16), True, False, out=out, beta=1.0)
     finally:
         _lib.load().mafed_gemm_set_variant(100)
+        _lib.load().mafed_gemm_set_variant(0)
     ref = c0.double() + A.double().t() @ B.double()
     assert maxerr(out, ref) == 0.0
 

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 500 python3 bench.py --dump-profile $OUT 2> $OUT/bench_stderr.log | tail -1 > $OUT/bench_line.json
 rm -rf gpurun_out/prof_kt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg > /dev/null 2>&1
 ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
 kt=$(find gpurun_out/prof_kt -name "*kernel_trace.csv" | head -1)
 python3 - "$ks" "$kt" $OUT <<'PY'
@@ -41,14 +41,14 @@ PY
 python3 tools/trace_timeline.py "$kt" 8 > $OUT/timeline.txt
 rm -rf gpurun_out/prof_kt
 # the same with every kernel alone on the chip (--no-overlap: one stream): what the per-kernel `*_no_overlap` figures of the line are checked against
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-overlap --no-pipeline-optimizer > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-overlap --no-pipeline-optimizer > /dev/null 2>&1
 ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
 python3 - "$ks" $OUT <<'PY'
 import csv, re, sys
 ks, out = sys.argv[1:3]
 short = lambda n: re.sub(r"\(.*", "", n).replace("void mafed::", "").replace("mafed::", "")
 with open(ks) as f, open(out + "/bench_no_overlap_kernel_stats.csv", "w") as g:
-    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-overlap --no-pipeline-optimizer   (1x MI355X; one stream)\n")
+    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-overlap --no-pipeline-optimizer   (1x MI355X; one stream)\n")
     g.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for row in csv.DictReader(f):
         g.write('"%s",%s,%s,%d,%s,%s,%s\n' % (short(row["Name"]), row["Calls"], row["TotalDurationNs"], float(row["AverageNs"]), row["Percentage"], row["MinNs"], row["MaxNs"]))
@@ -57,7 +57,7 @@ rm -rf gpurun_out/prof_kt
 python3 tools/step_timeline.py > $OUT/step_timeline_inlib.txt 2>/dev/null || true
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/prof_$c
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --steps 3 --warmup 2 > /dev/null 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/prof_$c -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --steps 3 --warmup 2 > /dev/null 2>&1
 done
 python3 - $OUT <<'PY'
 import csv, glob, json, sys
@@ -94,4 +94,14 @@ for shape in "0 1 9216 4096 1024" "0 0 9216 1024 4096"; do
   python3 tools/pmc_summary.py gpurun_out/prof_gemm_all gemm_bf16 > $OUT/gemm_pmc_$tag.json
   rm -rf gpurun_out/prof_gemm_0 gpurun_out/prof_gemm_1 gpurun_out/prof_gemm_2 gpurun_out/prof_gemm_all
 done
+# the three attention kernels at the step's shape (isolated launches), same three counter sets
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY" "SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32"; do
+  rm -rf gpurun_out/prof_attn_all/p$i
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/prof_attn_all/p$i -- python3 tools/attn_bench.py > /dev/null 2>&1
+  i=$((i+1))
+done
+python3 tools/pmc_summary.py gpurun_out/prof_attn_all attn_ > $OUT/attn_pmc.json
+rm -rf gpurun_out/prof_attn_all
+python3 tools/attn_bench.py > $OUT/attn_isolated.txt 2>/dev/null
 cat $OUT/bench_line.json | cut -c1-400
