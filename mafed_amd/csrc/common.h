@@ -147,7 +147,7 @@ __device__ __forceinline__ void erf_gauss_fast2(f32x2 x, f32x2& erf_z, f32x2& ga
   const f32x2 z = ax * 0.70710678118654752440f;
   const f32x2 den = z * 0.3275911f + 1.0f;
   f32x2 t;
-  t[0] = __frcp_rn(den[0]); t[1] = __frcp_rn(den[1]);
+  t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);  // v_rcp_f32 (1 ulp): __frcp_rn expands to the ~10-instruction correctly rounded division
   const f32x2 a = z * z * -1.4426950408889634f;  // exp(-z^2) = exp2(-z^2 * log2 e)
   gauss[0] = __builtin_amdgcn_exp2f(a[0]); gauss[1] = __builtin_amdgcn_exp2f(a[1]);
   f32x2 p = t * 1.061405429f + -1.453152027f;
@@ -177,7 +177,7 @@ __device__ __forceinline__ float gelu_erf_grad_fast(float x) {
 }
 
 // x * sigmoid(1.702 x): hidden_act "quick_gelu" of the OpenAI CLIP towers (transformers/activations.py QuickGELUActivation)
-__device__ __forceinline__ float quick_gelu(float x) { return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x)); }
 
 // modality class of a token row (mafed/methods/distillation.py:134-144): 0 = language (valid text), 1 = vision, 2 = none (pad)
 __device__ __forceinline__ int modality_class(int64_t row, int S, int P, int T, const int64_t* attention_mask) {

@@ -340,8 +340,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
   for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] += kt0 * a_step;
 #pragma unroll
   for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] += kt0 * b_step;
-  issue(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
+  if (ABL != 7) issue(0, 0);
+  for (int kt = 0; kt < (ABL == 7 ? 0 : nkt); ++kt) {
     if (ABL != 6) __syncthreads();  // (hipcc drains vmcnt(0) first) tile kt has landed for every wave; everyone is done with tile kt-1
     if (kt == 0) MAFED_TRACE_MARK(3);
     const bool more = kt + 1 < nkt;
@@ -437,13 +437,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
       return;
     }
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    EpiPre pre[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) epi_prefetch<CT>(epi, C, m0 + wm * 64 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[it]);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), j = lane & 7;
       const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
       const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      epilogue_store8<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v);
+      epilogue_store8_pre<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v, pre[it]);
       if (epi.colsum) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) cs[i] += v[i];
@@ -455,8 +458,17 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    EpiPre pre[2][6];  // bf16 slot only: pass 1's operands are requested before pass 0's stores go out
+#pragma unroll
+    for (int it = 0; it < 6; ++it)
+      epi_prefetch<CT, false>(epi, C, m0 + (wm * 6) * 16 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[0][it]);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it)
+          epi_prefetch<CT, false>(epi, C, m0 + (wm * 6 + 3) * 16 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[1][it]);
+      }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int row = t * 16 + (lane & 15);
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
         const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        epilogue_store8<CT>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v);
+        epilogue_store8_pre<CT, false>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v, pre[pass][it]);
         if (epi.colsum) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) cs[i] += v[i];
@@ -522,6 +534,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int mt0 = pass * 5, nmt = pass == 0 ? 5 : 4;
+      EpiPre pre[5];
+#pragma unroll
+      for (int it = 0; it < 5; ++it)
+        if (it < nmt) epi_prefetch<CT>(epi, C, m0 + mt0 * 16 + it * 16 + (lane >> 2), n0 + wn * 32 + 8 * (lane & 3), pre[it]);
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         if (t < nmt) {
@@ -541,7 +557,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
           const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j) ^ (row & 7)) << 2));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j + 1) ^ (row & 7)) << 2));
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          epilogue_store8<CT>(epi, C, m0 + mt0 * 16 + row, n0 + wn * 32 + 8 * j, v);
+          epilogue_store8_pre<CT>(epi, C, m0 + mt0 * 16 + row, n0 + wn * 32 + 8 * j, v, pre[it]);
           if (epi.colsum) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) cs[i] += v[i];
@@ -872,6 +888,9 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
     case 24: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 4>(M, N, K, A, lda, B, ldb, C, epi, st);
     case 25: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 5>(M, N, K, A, lda, B, ldb, C, epi, st);
     case 26: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 6>(M, N, K, A, lda, B, ldb, C, epi, st);
+    case 29: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 7>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x128, epilogue only (timing)
+    case 30: if constexpr (!A_KS) return launch_bf16_glds<1, 4, 9, 2, A_KS, B_KS, CT, 7>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, epilogue only (timing)
+    case 27: if constexpr (!A_KS) return launch_bf16_glds<2, 2, 6, 4, A_KS, B_KS, CT, 7>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 192x128, epilogue only (timing)
     case 9: return launch_bf16_ring<2, 2, 4, 4, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 128x128, BK 32, 2 stages (32 KiB): 4 blocks / CU
     case 10: return launch_bf16_ring<2, 2, 4, 4, 3, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x128, BK 32, 3 stages (48 KiB): 3 blocks / CU
     case 7: return launch_bf16_pipe<2, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);      // 128x128, pipelined fragment reads
@@ -986,10 +1005,12 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
       const bool ok144 = (M % 144 == 0) && (N % 128 == 0) && !a_ks, ok144x256 = (M % 144 == 0) && (N % 256 == 0) && !a_ks;
       if (((want == 11 || want == 12) && ok144) || (want == 13 && ok144x256)) cfg = want;
       else if (want == 16 && (M % 288 == 0) && (N % 256 == 0) && !a_ks) cfg = 16;
-      else if (want == 17 && (M % 192 == 0) && (N % 128 == 0) && !a_ks) cfg = 17;
+      else if ((want == 17 || want == 27) && (M % 192 == 0) && (N % 128 == 0) && !a_ks) cfg = want;
       else if (want == 14 && (M % 128 == 0) && (N % 64 == 0)) cfg = 14;
       else if (want == 15 && (M % 64 == 0) && (N % 128 == 0)) cfg = 15;
       else if (want == 18 && ok128 && c_dtype == MAFED_F32 && !colsum && (K / 64) % 2 == 0) cfg = 18;
+      else if (want == 29 && ok128) cfg = 29;
+      else if (want == 30 && ok144) cfg = 30;
       else if (((want == 0 || want == 3 || want == 6 || want == 7 || want == 9 || want == 10 || (want >= 21 && want <= 26)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
       else if (ok128) cfg = 0;
     } else {

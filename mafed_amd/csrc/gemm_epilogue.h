@@ -126,6 +126,102 @@ __device__ __forceinline__ void epilogue_store8(const GemmEpi& e, CT* __restrict
   store8(C + off, v);
 }
 
+// Operands the epilogue READS per 8-column group (saved pre-activation of GELU', residuals, the old C of beta != 0), fetched for a
+// whole pass of groups BEFORE that pass's stores: inside epilogue_store8 each load sits behind the previous group's store (the
+// compiler cannot prove C / aux / residual pointers distinct), so a wave paid one HBM round trip per group -- 12 in a row in
+// the GELU' GEMM, whose epilogue alone ran 55 us for 151 MB.  One bf16 slot (aux, or the bf16 residual) and one fp32 slot
+// (res2, or the old C) per group; whatever does not fit a slot is loaded in place as before.
+struct EpiPre {
+  uint4 h;        // 8 bf16
+  float4 f0, f1;  // 8 fp32
+};
+template <typename CT>
+__device__ __forceinline__ bool epi_pre_aux(const GemmEpi& e) { return sizeof(CT) == 2 && e.mode == MAFED_EPI_GELU_BWD; }
+template <typename CT>
+__device__ __forceinline__ bool epi_pre_res1(const GemmEpi& e) { return e.res1 && e.res1_bf16 && !epi_pre_aux<CT>(e); }
+template <typename CT>
+__device__ __forceinline__ bool epi_pre_cold(const GemmEpi& e) { return sizeof(CT) == 4 && e.beta != 0.f && !e.res2; }
+
+// F32SLOT = false: only the bf16 slot is fetched ahead (tiles whose accumulators leave no room for 8 more registers per group)
+template <typename CT, bool F32SLOT = true>
+__device__ __forceinline__ void epi_prefetch(const GemmEpi& e, const CT* __restrict__ C, int64_t m, int64_t n, EpiPre& p) {
+  const int64_t off = m * e.ldc + n;
+  if (epi_pre_aux<CT>(e)) p.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(e.aux) + off);
+  else if (epi_pre_res1<CT>(e)) p.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(e.res1) + off);
+  if (!F32SLOT) return;
+  if (e.res2) {
+    p.f0 = load4(e.res2 + off);
+    p.f1 = load4(e.res2 + off + 4);
+  } else if (epi_pre_cold<CT>(e)) {
+    p.f0 = load4(reinterpret_cast<const float*>(C) + off);
+    p.f1 = load4(reinterpret_cast<const float*>(C) + off + 4);
+  }
+}
+
+__device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// epilogue_store8 with the read operands taken from `p` (same arithmetic, same order of additions)
+template <typename CT, bool F32SLOT = true>
+__device__ __forceinline__ void epilogue_store8_pre(const GemmEpi& e, CT* __restrict__ C, int64_t m, int64_t n, float (&v)[8], const EpiPre& p) {
+  const int64_t off = m * e.ldc + n;
+  if (e.bias) {
+    float b[8];
+    load8(e.bias + n, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (e.mode == MAFED_EPI_GELU) {
+    if (e.aux) store8(reinterpret_cast<CT*>(e.aux) + off, v);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const f32x2 r = gelu_erf_fast2((f32x2){v[i], v[i + 1]});
+      v[i] = r[0]; v[i + 1] = r[1];
+    }
+  } else if (e.mode == MAFED_EPI_QUICK_GELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = quick_gelu(v[i]);
+  } else if (e.mode == MAFED_EPI_GELU_BWD) {
+    float u[8];
+    if (epi_pre_aux<CT>(e)) unpack8(p.h, u);
+    else load8(reinterpret_cast<const CT*>(e.aux) + off, u);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const f32x2 r = gelu_erf_grad_fast2((f32x2){u[i], u[i + 1]});
+      v[i] *= r[0]; v[i + 1] *= r[1];
+    }
+  }
+  if (e.res1) {
+    float r[8];
+    if (epi_pre_res1<CT>(e)) unpack8(p.h, r);
+    else if (e.res1_bf16) load8(reinterpret_cast<const bf16_t*>(e.res1) + off, r);
+    else load8(e.res1 + off, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (e.res2) {
+    float r[8] = {p.f0.x, p.f0.y, p.f0.z, p.f0.w, p.f1.x, p.f1.y, p.f1.z, p.f1.w};
+    if (!F32SLOT) load8(e.res2 + off, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (e.beta != 0.f) {
+    float c[8];
+    if (F32SLOT && epi_pre_cold<CT>(e)) {
+      c[0] = p.f0.x; c[1] = p.f0.y; c[2] = p.f0.z; c[3] = p.f0.w; c[4] = p.f1.x; c[5] = p.f1.y; c[6] = p.f1.z; c[7] = p.f1.w;
+    } else {
+      load8(C + off, c);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += e.beta * c[i];
+  }
+  store8(C + off, v);
+}
+
 // Fused column sums of the stored tile: cs[i] holds this lane's partial for column 8*(lane % JL)+i over the rows it
 // stored; lanes that share lane % JL are folded, then JL lanes issue 8 atomics each (one per column per wave per tile).
 template <int JL>
