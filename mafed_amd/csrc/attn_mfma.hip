@@ -19,11 +19,23 @@ namespace {
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-// [rows][D] bf16 image, 16-byte chunk swizzle (row reads with ds_read_b128 and transposing reads share it)
+// [rows][D] bf16 image, 16-byte chunk swizzle (row reads with ds_read_b128 and transposing reads share it).
+// swz<D>(row) only moves aligned 32-byte chunk PAIRS (its low bit is 0), by a value that differs over the rows of every aligned
+// group of 8 that share a 256-byte bank row -- D = 64: two rows per bank row, pair index ^ (row >> 1 & 3); D = 128: one row per bank
+// row, pair index ^ (row & 7).  Then the 8 x 32-byte pieces of a ds_read_b64_tr_b16 lane group fall on 8 distinct 32-byte slots and
+// the 16 lanes of a ds_read_b128 group (rows {0-3, 12-15} at chunk c, rows {4-11} at chunk c ^ 1) on 16 distinct 16-byte slots:
+// SQ_LDS_BANK_CONFLICT 0 for both (the round-1 functions (row >> 1) & 7 and (row & 3) << 2 | (row >> 2) & 3 paired rows j and j + 2
+// resp. j + 4 on the same slot: every transposing read took two LDS cycles per lane group, profiles/r01_attn_pmc.json).
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if (D == 64) return ((row >> 1) & 3) << 1;
+  if (D == 128) return (row & 7) << 1;
+  return ((row & 7) << 1) | ((row >> 3) & 1);
+}
 template <int D>
 __device__ __forceinline__ int tile_off(int row, int chunk) {
-  if (D == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-  if (D == 128) return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+  if (D == 64) return row * 128 + ((chunk ^ swz<64>(row)) << 4);
+  if (D == 128) return row * 256 + ((chunk ^ swz<128>(row)) << 4);
   // D = 256 (VLPythia-1B): 512-byte rows, the low four chunk bits XORed with f(row) = (row & 7) << 1 | (row >> 3) & 1 -- a bijection
   // on every aligned group of 16 rows (row reads of one chunk hit 16 distinct 16-byte slots) whose upper three bits differ over
   // every aligned group of 8 rows (the 8 x 32-byte pieces of a transposing read hit 8 distinct 32-byte slots)
@@ -533,10 +545,10 @@ __device__ __forceinline__ void dma_rows(char* __restrict__ img, const bf16_t* _
     int row, logical;
     if (D == 64) {
       row = j * 8 + (lane >> 3);
-      logical = (lane & 7) ^ ((row >> 1) & 7);
+      logical = (lane & 7) ^ swz<64>(row);
     } else {
       row = j * 4 + (lane >> 4);
-      logical = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      logical = (lane & 15) ^ swz<128>(row);
     }
     const int srow = row < S ? row : S - 1;
     __builtin_amdgcn_global_load_lds((glb_void_ptr)(base + (int64_t)srow * rstride + logical * 8), (lds_void_ptr)(img + j * 1024), 16, 0, 0);

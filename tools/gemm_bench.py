@@ -21,7 +21,7 @@ SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
     ("wqkv  TN", True, False, 3072, 1024, M, torch.float32),
     ("wdns  TN", True, False, 1024, 1024, M, torch.float32),
     ("head  NT", False, True, 1024, 50304, 1024, torch.bfloat16),
-    ("dlnf  NN", False, False, 1024, 1024, 50304, torch.bfloat16),
+    ("dlnf  NN", False, False, 1024, 1024, 50304, torch.float32),   # LM-head dX: accumulate-only fp32 output, K split (as model.py issues it)
     ("proj  NT", False, True, 8192, 1024, 1024, torch.bfloat16),
 ]
 EPI = os.environ.get("GEMM_BENCH_EPI", "0") == "1"   # fc1 with bias + GELU + saved pre-activation, dfc2 with GELU'
@@ -41,7 +41,7 @@ for name, tA, tB, m, n, k, od in SHAPES:
     B = torch.randn((n, k) if tB else (k, n), device=dev, generator=g).to(torch.bfloat16)
     out = torch.zeros((m, n), dtype=od, device=dev)
     ref = None
-    beta = 1.0 if (tA and od == torch.float32) else 0.0   # weight-gradient GEMMs accumulate into the gradient buffer
+    beta = 1.0 if ((tA or name.startswith("dlnf")) and od == torch.float32) else 0.0   # weight-gradient GEMMs accumulate into the gradient buffer
     kw = {}
     if EPI and name.startswith("fc1"):
         kw = dict(bias=torch.randn(n, device=dev), epilogue=ops.EPI_GELU, aux=torch.empty((m, n), dtype=od, device=dev))
