@@ -320,87 +320,139 @@ __device__ __forceinline__ void load_chunk_rot8(const T* __restrict__ row, int c
   for (int e = 0; e < 8; ++e) o[e] = first ? o[e] * cp[e] - y[e] * sp[e] : o[e] * cp[e] + y[e] * sp[e];
 }
 
+__device__ __forceinline__ void unpack_bf16x8(const uint4& r, float (&v)[8]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// One pass over the K/V cache: `chunks` = D/8 lanes share a key row (lane c takes the 16-byte chunk c of k AND of v: the row's k | v
+// are 4*D contiguous bytes), 256/chunks rows per step and four steps of loads in flight per thread; the row's score is folded over
+// those lanes with DPP/permute adds and every row group keeps an online-softmax state (m, l, acc[8]) that the block merges at the
+// end.  Replaces the thread-per-key / exp / V three-phase form (19 us at B = 32, S = 288: its 256 threads covered 289+ keys in two
+// dependent rounds, the second one with 33 busy lanes).
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_decode_block_kernel(const T* __restrict__ qkv_pre, int S0, const T* __restrict__ qkv_new, int cap, int t,
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restrict__ qkv_pre, int S0, const T* __restrict__ qkv_new, int cap, int t,
                                                                 int H, int rot, int P, int Tm, const float* __restrict__ rc,
                                                                 const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                                 T* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // q[D] | sc[nk] | red[groups][D] | 8 reduction slots
   constexpr int chunks = D / 8, groups = 256 / chunks;
+  __shared__ float q_s[D];
+  __shared__ float red[groups][D];
+  __shared__ float ml[groups][2];
   const int tid = threadIdx.x;
   const int h = blockIdx.x, b = blockIdx.y;
   const int nk = S0 + t + 1;
-  float* q = lds;
-  float* sc = q + D;
-  float* red = sc + ((nk + 3) & ~3);
-  float* sm = red + groups * D;
   const int64_t rstride = (int64_t)H * 3 * D;
   const T* pre = qkv_pre + ((int64_t)b * S0 * H + h) * 3 * D;
   const T* neu = qkv_new + ((int64_t)b * cap * H + h) * 3 * D;
-  if (tid < chunks) {
-    float v[8];
-    load_chunk_rot8<T>(neu + (int64_t)t * rstride, tid, rot, rc, rs, S0 + t, v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q[tid * 8 + e] = v[e];
-  }
-  __syncthreads();
-  const float scale = rsqrtf((float)D);
-  float m = -INFINITY;
-  for (int j = tid; j < nk; j += 256) {
-    float s = -INFINITY;
-    if (j >= S0 || key_valid(am, b, j, P, Tm)) {
-      const T* kp = (j < S0 ? pre + (int64_t)j * rstride : neu + (int64_t)(j - S0) * rstride) + D;
-      float kv[chunks][8];
-#pragma unroll
-      for (int c = 0; c < chunks; ++c) load_chunk_rot8<T>(kp, c, rot, rc, rs, j, kv[c]);  // the whole row in flight at once
-      float acc = 0.f;
-#pragma unroll
-      for (int c = 0; c < chunks; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], kv[c][e], acc);
-      s = acc * scale;
-    }
-    sc[j] = s;
-    m = fmaxf(m, s);
-  }
-  m = block_max<256>(m, sm);
-  float l = 0.f;
-  for (int j = tid; j < nk; j += 256) {
-    const float p = expf(sc[j] - m);
-    sc[j] = p;
-    l += p;
-  }
-  l = block_sum<256>(l, sm);  // (the barriers inside also publish sc[])
   const int c = tid % chunks, kg = tid / chunks;
+  const float scale = rsqrtf((float)D);
+  float qr[8];
+  constexpr int UNR = D == 64 ? 5 : 4;  // rows in flight per thread: 5 x 32 row groups cover S <= 320 keys in two steps
+  float m = -INFINITY, l = 0.f;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto vrow = [&](int j) { return (j < S0 ? pre + (int64_t)j * rstride : neu + (int64_t)(j - S0) * rstride) + 2 * D + c * 8; };
-  int j = kg;
-  for (; j + 3 * groups < nk; j += 4 * groups) {  // four V rows in flight per thread
-    float v[4][8];
+  // Every load of a step is unconditional (clamped row, partner chunk and cos / sin rows fetched by every lane, the mask word too) and
+  // the selects come afterwards: with the loads inside `if (valid)` / `if (chunk < rot)` regions the compiler drained vmcnt(0) at the
+  // end of each region -- mask word -> k chunk -> rotary operands -> v chunk became four dependent round trips per row.
+  const int hc = rot >> 4, half = rot >> 1;
+  const bool inrot = c * 8 < rot, first = c < hc;
+  const int cpart = inrot ? (first ? c + hc : c - hc) : c;     // rotary partner chunk (itself outside the rotary range)
+  const int ccs = inrot ? (first ? c : c - hc) * 8 : 0;       // offset into the cos / sin row
+  const float sgn = first ? -1.f : 1.f;
+  int j0 = kg;
+  do {  // at least one step per thread (rows past nk are clamped loads with p = 0): the barrier below is reached by every thread
+    uint4 kraw[UNR], praw[UNR], vraw[UNR];
+    float4 cs0[UNR], cs1[UNR], sn0[UNR], sn1[UNR];
+    int64_t amv[UNR];
+    int jj[UNR];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_row8<T>(vrow(j + u * groups), v[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float p = sc[j + u * groups];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[u][e], acc[e]);
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * groups;
+      const int jc = j < nk ? j : nk - 1;
+      jj[u] = j;
+      const T* row = jc < S0 ? pre + (int64_t)jc * rstride : neu + (int64_t)(jc - S0) * rstride;
+      if constexpr (sizeof(T) == 2) {
+        kraw[u] = *reinterpret_cast<const uint4*>(row + D + c * 8);
+        praw[u] = *reinterpret_cast<const uint4*>(row + D + cpart * 8);
+        vraw[u] = *reinterpret_cast<const uint4*>(row + 2 * D + c * 8);
+      }
+      const float* cp = rc + (int64_t)jc * half + ccs;
+      const float* sp = rs + (int64_t)jc * half + ccs;
+      cs0[u] = load4(cp); cs1[u] = load4(cp + 4); sn0[u] = load4(sp); sn1[u] = load4(sp + 4);
+      const int ti = jc >= P && jc < S0 ? jc - P : 0;
+      amv[u] = am[(int64_t)b * Tm + ti];
     }
-  }
-  for (; j < nk; j += groups) {
-    float v[8];
-    load_row8<T>(vrow(j), v);
-    const float p = sc[j];
+    if (j0 == kg) {
+      // the query row is fetched and rotated behind the first step's K / V requests (they do not depend on it); every thread takes
+      // this branch in its first iteration, so the barrier is reached by the whole block
+      if (tid < chunks) {
+        float v[8];
+        load_chunk_rot8<T>(neu + (int64_t)t * rstride, tid, rot, rc, rs, S0 + t, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[e], acc[e]);
-  }
+        for (int e = 0; e < 8; ++e) q_s[tid * 8 + e] = v[e];
+      }
+      __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[kg * D + c * 8 + e] = acc[e];
+      for (int e = 0; e < 8; ++e) qr[e] = q_s[c * 8 + e] * scale;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = jj[u];
+      const bool ok = j < nk && (j < P || j >= S0 || amv[u] != 0);
+      float x[8], y[8], vv[8];
+      if constexpr (sizeof(T) == 2) {
+        unpack_bf16x8(kraw[u], x);
+        unpack_bf16x8(praw[u], y);
+        unpack_bf16x8(vraw[u], vv);
+      } else {
+        const int jc = j < nk ? j : nk - 1;
+        const T* row = jc < S0 ? pre + (int64_t)jc * rstride : neu + (int64_t)(jc - S0) * rstride;
+        load_row8<T>(row + D + c * 8, x);
+        load_row8<T>(row + D + cpart * 8, y);
+        load_row8<T>(row + 2 * D + c * 8, vv);
+      }
+      const float cs[8] = {cs0[u].x, cs0[u].y, cs0[u].z, cs0[u].w, cs1[u].x, cs1[u].y, cs1[u].z, cs1[u].w};
+      const float sn[8] = {sn0[u].x, sn0[u].y, sn0[u].z, sn0[u].w, sn1[u].x, sn1[u].y, sn1[u].z, sn1[u].w};
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float kr = inrot ? x[e] * cs[e] + sgn * y[e] * sn[e] : x[e];
+        s = fmaf(qr[e], kr, s);
+      }
+#pragma unroll
+      for (int o = 1; o < chunks; o <<= 1) s += __shfl_xor(s, o, 64);
+      // masked or out-of-range rows: p = 0 and the state is left as it is (selects, no branches)
+      const float mn = ok ? fmaxf(m, s) : m;
+      const float corr = (ok && m != -INFINITY) ? expf(m - mn) : (ok ? 0.f : 1.f);
+      const float p = ok ? expf(s - mn) : 0.f;
+      l = l * corr + p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(acc[e], corr, p * vv[e]);
+      m = mn;
+    }
+    j0 += UNR * groups;
+  } while (j0 < nk);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[kg][c * 8 + e] = acc[e];
+  if (c == 0) {
+    ml[kg][0] = m;
+    ml[kg][1] = l;
+  }
   __syncthreads();
   if (tid < D) {
-    float o = 0.f;
+    float mx = -INFINITY;
 #pragma unroll 8
-    for (int g2 = 0; g2 < groups; ++g2) o += red[g2 * D + tid];
-    Elem<T>::store(out + (int64_t)b * H * D + (int64_t)h * D + tid, o / l);
+    for (int g2 = 0; g2 < groups; ++g2) mx = fmaxf(mx, ml[g2][0]);
+    float o = 0.f, lt = 0.f;
+#pragma unroll 8
+    for (int g2 = 0; g2 < groups; ++g2) {
+      const float w = ml[g2][0] == -INFINITY ? 0.f : expf(ml[g2][0] - mx);  // a group whose rows were all masked contributes nothing
+      o = fmaf(w, red[g2][tid], o);
+      lt = fmaf(w, ml[g2][1], lt);
+    }
+    Elem<T>::store(out + (int64_t)b * H * D + (int64_t)h * D + tid, o / lt);
   }
 }
 
@@ -408,21 +460,12 @@ template <typename T>
 int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
                        const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st) {
   if (rot % 16 == 0 && (D == 64 || D == 128 || D == 256)) {
-    const int nk = S0 + t + 1, groups = 256 / (D / 8);
-    const size_t lb = ((size_t)D + ((nk + 3) & ~3) + (size_t)groups * D + 8) * sizeof(float);
-    if (lb <= 160 * 1024) {
-#define GO(DV)                                                                                                                      \
-  do {                                                                                                                              \
-    auto kb = attn_decode_block_kernel<T, DV>;                                                                                      \
-    if (lb > 64 * 1024) (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);            \
-    kb<<<dim3(H, B), dim3(256), lb, st>>>((const T*)qkv_pre, S0, (const T*)qkv_new, cap, t, H, rot, P, Tm, rc, rs, am, (T*)out);   \
-  } while (0)
-      if (D == 64) GO(64);
-      else if (D == 128) GO(128);
-      else GO(256);
+#define GO(DV) attn_decode_fused_kernel<T, DV><<<dim3(H, B), dim3(256), 0, st>>>((const T*)qkv_pre, S0, (const T*)qkv_new, cap, t, H, rot, P, Tm, rc, rs, am, (T*)out)
+    if (D == 64) GO(64);
+    else if (D == 128) GO(128);
+    else GO(256);
 #undef GO
-      return MAFED_OK;
-    }
+    return MAFED_OK;
   }
   const size_t lds = (size_t)4 * (D + S0 + t + 1) * sizeof(float);
   if (lds > 160 * 1024) { set_error("attn_decode: %d keys too many for this kernel", S0 + t + 1); return MAFED_EINVAL; }

@@ -926,7 +926,10 @@ static int g_gemm_variant = 0;
 static int g_gemm_big = 0;    // 288x256 configuration in automatic mode (200 = off, 201 = on): faster alone, slower beside the side streams
 static int g_gemm_kgroups = 0;  // two K groups per block for the one-tile-per-CU weight gradients (400 = off, 401 = on): 9 % faster alone, 2.5 % slower step (no dX block fits beside a 128 KiB block)
 static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
+namespace mafed { extern int g_skinny_ns, g_skinny_wide; }
 extern "C" int mafed_gemm_set_variant(int v) {
+  if (v >= 600) { g_skinny_wide = v == 699 ? -1 : v - 600; return MAFED_OK; }
+  if (v >= 500) { g_skinny_ns = v - 500; return MAFED_OK; }
   if (v >= 400) { g_gemm_kgroups = v - 400; return MAFED_OK; }
   if (v >= 300) { g_gemm_group_m = v - 300 > 0 ? v - 300 : 1; return MAFED_OK; }
   if (v >= 200) { g_gemm_big = v - 200; return MAFED_OK; }

@@ -16,23 +16,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave;
   if (row >= rows) return;
   const float* xr = x + row * h;
-  float4 v[NV];
-  float s = 0.f;
+  // Every load of the row is issued up front and unconditionally (columns past h re-read column 0 and are discarded by selects):
+  // with the loads inside `c < h` regions the compiler drained vmcnt(0) at the end of every region -- four dependent HBM round trips
+  // for x, then eight dependent L2 round trips for the affine parameters, per wave.
+  float4 v[NV], g1[NV], o1[NV], g2[NV], o2[NV];
+  bool in[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    v[i] = (c < h) ? load4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    in[i] = c < h;
+    v[i] = load4(xr + (in[i] ? c : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = in[i] ? (lane + 64 * i) * 4 : 0;
+    g1[i] = load4(w1 + c);
+    o1[i] = load4(b1 + c);
+    if (y2) {  // uniform
+      g2[i] = load4(w2 + c);
+      o2[i] = load4(b2 + c);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (!in[i]) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(s) / (float)h;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < h) {
-      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-      q += (a * a + b * b) + (cc * cc + d * d);
-    }
+    const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+    q += in[i] ? (a * a + b * b) + (cc * cc + d * d) : 0.f;
   }
   const float var = wave_sum(q) / (float)h;
   const float rstd = 1.0f / sqrtf(var + eps);
@@ -43,14 +59,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    if (c < h) {
+    if (in[i]) {
       float4 n = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
-      const float4 g1 = load4(w1 + c), o1 = load4(b1 + c);
-      store4(y1 + row * h + c, make_float4(n.x * g1.x + o1.x, n.y * g1.y + o1.y, n.z * g1.z + o1.z, n.w * g1.w + o1.w));
-      if (y2) {
-        const float4 g2 = load4(w2 + c), o2 = load4(b2 + c);
-        store4(y2 + row * h + c, make_float4(n.x * g2.x + o2.x, n.y * g2.y + o2.y, n.z * g2.z + o2.z, n.w * g2.w + o2.w));
-      }
+      store4(y1 + row * h + c, make_float4(n.x * g1[i].x + o1[i].x, n.y * g1[i].y + o1[i].y, n.z * g1[i].z + o1[i].z, n.w * g1[i].w + o1[i].w));
+      if (y2) store4(y2 + row * h + c, make_float4(n.x * g2[i].x + o2[i].x, n.y * g2[i].y + o2[i].y, n.z * g2[i].z + o2[i].z, n.w * g2[i].w + o2[i].w));
     }
   }
 }
