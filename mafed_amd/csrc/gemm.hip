@@ -438,6 +438,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
     }
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     EpiPre pre[8];
+    float bv[8];
+    epi_bias8(epi, n0 + wn * 64 + 8 * (lane & 7), bv);
 #pragma unroll
     for (int it = 0; it < 8; ++it) epi_prefetch<CT>(epi, C, m0 + wm * 64 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[it]);
 #pragma unroll
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
       const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
       const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      epilogue_store8_pre<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v, pre[it]);
+      epilogue_store8_pre<CT>(epi, C, m0 + wm * 64 + row, n0 + wn * 64 + 8 * j, v, pre[it], bv);
       if (epi.colsum) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) cs[i] += v[i];
@@ -458,6 +460,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bv[8];
+    epi_bias8(epi, n0 + wn * 64 + 8 * (lane & 7), bv);
     EpiPre pre[2][6];  // bf16 slot only: pass 1's operands are requested before pass 0's stores go out
 #pragma unroll
     for (int it = 0; it < 6; ++it)
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
         const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        epilogue_store8_pre<CT, false>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v, pre[pass][it]);
+        epilogue_store8_pre<CT, false>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v, pre[pass][it], bv);
         if (epi.colsum) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) cs[i] += v[i];
@@ -531,6 +535,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 2560;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bv[8];
+    epi_bias8(epi, n0 + wn * 32 + 8 * (lane & 3), bv);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int mt0 = pass * 5, nmt = pass == 0 ? 5 : 4;
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
           const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j) ^ (row & 7)) << 2));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 32 + (((2 * j + 1) ^ (row & 7)) << 2));
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          epilogue_store8_pre<CT>(epi, C, m0 + mt0 * 16 + row, n0 + wn * 32 + 8 * j, v, pre[it]);
+          epilogue_store8_pre<CT>(epi, C, m0 + mt0 * 16 + row, n0 + wn * 32 + 8 * j, v, pre[it], bv);
           if (epi.colsum) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) cs[i] += v[i];

@@ -166,14 +166,23 @@ __device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {
 }
 
 // epilogue_store8 with the read operands taken from `p` (same arithmetic, same order of additions)
+// `bv`: the 8 bias values of columns n .. n+7, loaded ONCE per wave by the caller (epi_bias8): the column group of a lane is the same
+// for every row group and pass of the tile, but a reload after each store (the compiler cannot hoist it past them) put an L2 round
+// trip on the dependency chain of every group.
+__device__ __forceinline__ void epi_bias8(const GemmEpi& e, int64_t n, float (&bv)[8]) {
+  if (e.bias) load8(e.bias + n, bv);
+  else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = 0.f;
+  }
+}
 template <typename CT, bool F32SLOT = true>
-__device__ __forceinline__ void epilogue_store8_pre(const GemmEpi& e, CT* __restrict__ C, int64_t m, int64_t n, float (&v)[8], const EpiPre& p) {
+__device__ __forceinline__ void epilogue_store8_pre(const GemmEpi& e, CT* __restrict__ C, int64_t m, int64_t n, float (&v)[8], const EpiPre& p,
+                                                    const float (&bv)[8]) {
   const int64_t off = m * e.ldc + n;
   if (e.bias) {
-    float b[8];
-    load8(e.bias + n, b);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += b[i];
+    for (int i = 0; i < 8; ++i) v[i] += bv[i];
   }
   if (e.mode == MAFED_EPI_GELU) {
     if (e.aux) store8(reinterpret_cast<CT*>(e.aux) + off, v);
