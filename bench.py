@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-image-leg", action="store_true", help="skip the image-input measurement (CLIP-ViT-L/14 tower in front of the step)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
+    ap.add_argument("--no-incremental-norm", action="store_true", help="clip norm in one pass at the start of the optimiser step (A/B)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
     ap.add_argument("--reduce-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
@@ -204,7 +205,7 @@ def main():
     conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=1, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_perc=0.1)
     tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
-                 bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt)
+                 bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt, incremental_norm=not args.no_incremental_norm)
     task_batch = mem.sample()  # dropped by a replay step, as in the reference
 
     def barrier():
@@ -279,7 +280,7 @@ def main():
                                       weight_decay=0.01, optim="adamw", warmup_perc=0.1)
         student.zero_grad()
         tr2 = Trainer(student, fd, conf2, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
-                      bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt)
+                      bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt, incremental_norm=not args.no_incremental_norm)
         task2 = [mem2._draw() for _ in range(4)]   # current-task micro-batches (synthetic, resident in HBM)
         n_opt = max(3, args.steps // 4)
         for i in range(8):                          # two untimed optimiser steps
@@ -338,7 +339,7 @@ def main():
         fd.mem_dataloader = _Cycle()
         fd.batch_size = B
         tr3 = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
-                      bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt)
+                      bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt, incremental_norm=not args.no_incremental_norm)
         n3 = max(5, args.steps // 2)
         for i in range(3):
             tr3.step(task_batch, i)

@@ -205,6 +205,12 @@ int mafed_distill_cls_bwd(const float* s, const float* t, int B, int S, int h, c
 size_t mafed_gradnorm_workspace_bytes(int64_t n);
 int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, float* out2, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* The same norm in pieces: mafed_gradnorm_partial writes mafed_gradnorm_blocks(n) sum-of-squares partials of one range (call it as soon
+ * as that range of the gradient is final, on the stream that finished it); mafed_gradnorm_finish folds n_partials of them (index
+ * order) into out2 = {norm, clip scale}.  Replaces the single pass over the whole buffer at the start of the optimiser step. */
+int mafed_gradnorm_blocks(int64_t n);
+int mafed_gradnorm_partial(const float* g, int64_t n, float* partial_out, void* stream);
+int mafed_gradnorm_finish(const float* partial, int n_partials, float max_norm, float* out2, void* stream);
 /* HF-style AdamW on a flat segment (mafed/optim/adamw.py:86-111): m,v update; denom = sqrt(v) + eps (not bias
  * corrected); p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/denom; then p -= lr*wd*p.  g is multiplied by clip_scale_dev[1]
  * (from mafed_gradnorm_clip) and by grad_mul (1/world for DDP means).  lr_dev: device scalar (scheduled lr).

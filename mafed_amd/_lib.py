@@ -49,6 +49,9 @@ SIGNATURES = {
     "mafed_distill_cls_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "mafed_gradnorm_workspace_bytes": (_z, [_l]),
     "mafed_gradnorm_clip": (_i, [_p, _l, _f, _p, _p, _z, _p]),
+    "mafed_gradnorm_blocks": (_i, [_l]),
+    "mafed_gradnorm_partial": (_i, [_p, _l, _p, _p]),
+    "mafed_gradnorm_finish": (_i, [_p, _i, _f, _p, _p]),
     "mafed_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
     "mafed_adamw_step_zero_grad": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
     "mafed_distill_combine": (_i, [_p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p]),

@@ -143,6 +143,32 @@ extern "C" int mafed_gradnorm_clip(const float* g, int64_t n, float max_norm, fl
   return MAFED_OK;
 }
 
+// Piecewise form of the same norm: sum-of-squares partials of one range of the gradient buffer (as soon as that range is final,
+// on whatever stream finished it), then one finish over all partials.  With these the optimiser step keeps only the last range and
+// the finish on its critical path instead of a 1.6 GB pass (0.28 ms at 410M).  Deterministic: every range has a fixed block count
+// and the finish adds the partials in index order.
+extern "C" int mafed_gradnorm_blocks(int64_t n) {
+  int64_t nb = cdiv(n / 4 + 1, 256 * 4);
+  if (nb > GN_BLOCKS) nb = GN_BLOCKS;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int mafed_gradnorm_partial(const float* g, int64_t n, float* partial_out, void* stream) {
+  MAFED_CHECK_ARG(g && partial_out && n >= 0, "gradnorm_partial: bad arguments");
+  MAFED_CHECK_ARG(((uintptr_t)g & 15) == 0, "gradnorm_partial: g must be 16-byte aligned");
+  launch(K_GRADNORM, (double)n * 4.0, gradnorm_partial_kernel, dim3((unsigned)mafed_gradnorm_blocks(n)), dim3(256), 0, as_stream(stream), g, n, partial_out);
+  MAFED_CHECK_LAUNCH("gradnorm_partial");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_gradnorm_finish(const float* partial, int n_partials, float max_norm, float* out2, void* stream) {
+  MAFED_CHECK_ARG(partial && out2 && n_partials >= 1, "gradnorm_finish: bad arguments");
+  launch(K_SMALL, 0.0, gradnorm_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, n_partials, max_norm, out2);
+  MAFED_CHECK_LAUNCH("gradnorm_finish");
+  return MAFED_OK;
+}
+
 static int adamw_impl(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
                       float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16, bool zero_g, void* stream) {
   MAFED_CHECK_ARG(p && g && m && v && lr_dev && n >= 0 && step >= 0, "adamw_step: bad arguments");

@@ -57,6 +57,7 @@ class CLStrategy:
 
 class Naive(CLStrategy):
     """Plain fine-tuning: the task loss is returned untouched (mafed/methods/base.py:50-57)."""
+    grads_only_through_model = True  # every parameter gradient of a step comes out of the model's own backward (Trainer: incremental clip norm)
 
     def __init__(self, **kwargs):
         super().__init__(**kwargs)

@@ -99,6 +99,7 @@ class _DistillClsFn(torch.autograd.Function):
 
 class FeatureDistillation(CLStrategy):
     """Feature Distillation with Separate Vision & Language Weights (MAFED)."""
+    grads_only_through_model = True  # every parameter gradient of a step comes out of the model's own backward (Trainer: incremental clip norm)
 
     def __init__(self, memory_size, opts, model_type, distillation_modality_weighing_strategy="equal",
                  distillation_layer_weighing_strategy="single", distillation_coeff=1.0, replay_coeff=1.0,

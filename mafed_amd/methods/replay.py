@@ -9,6 +9,7 @@ from mafed_amd.methods.memory import HBMReplayBuffer
 
 
 class ER(CLStrategy):
+    grads_only_through_model = True  # every parameter gradient of a step comes out of the model's own backward (Trainer: incremental clip norm)
     def __init__(self, opts, memory_size, model_type, **kwargs):
         super().__init__(opts=opts, **{k: v for k, v in kwargs.items() if k in ("reg_lambda", "mask", "scaler")})
         self.memory_size = memory_size

@@ -635,6 +635,7 @@ class VLPythiaForCausalLM(nn.Module):
         return {l: t.view(sv["B"], S, -1) for l, t in taps.items()}
 
     def _engine_backward(self, sv, dloss: Optional[torch.Tensor], dhidden: Sequence[Optional[torch.Tensor]], taps=None):
+        self._bw_serial = getattr(self, "_bw_serial", 0) + 1   # lets a gradient hook tell which backward sweep reported a range
         cfg, cd = self.config, self.compute_dtype
         B, T, P, S = sv["B"], sv["T"], sv["P"], sv["S"]
         h, H, D, L = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers

@@ -337,6 +337,20 @@ def gradnorm_clip(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor]
     return out2
 
 
+def gradnorm_blocks(n: int) -> int:
+    return int(_lib.load().mafed_gradnorm_blocks(int(n)))
+
+
+def gradnorm_partial(g: torch.Tensor, partial_out: torch.Tensor) -> None:
+    """sum-of-squares partials of the (contiguous, 16-byte aligned) range ``g`` -> partial_out[:gradnorm_blocks(g.numel())]"""
+    check(_lib.load().mafed_gradnorm_partial(_ptr(g), g.numel(), _ptr(partial_out), _stream()), "mafed_gradnorm_partial")
+
+
+def gradnorm_finish(partials: torch.Tensor, max_norm: float, out2: torch.Tensor) -> torch.Tensor:
+    check(_lib.load().mafed_gradnorm_finish(_ptr(partials), partials.numel(), float(max_norm), _ptr(out2), _stream()), "mafed_gradnorm_finish")
+    return out2
+
+
 def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None, zero_grad: bool = False) -> None:
     """``zero_grad``: the kernel also writes zeros over ``g`` (the next window's optimizer.zero_grad(), same pass)."""
     fn = _lib.load().mafed_adamw_step_zero_grad if zero_grad else _lib.load().mafed_adamw_step

@@ -83,9 +83,66 @@ class FlatAdamW:
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.model.flat_grads.zero_()
 
+    # ---- global-norm clip ------------------------------------------------------------------------------------------------
+    def _norm_plan(self):
+        """{trigger id: [(lo, hi, first partial slot), ...]} over the flat gradient buffer, in the order the backward finishes the
+        ranges (LM head = L, layers L-1 .. 0, embeddings / projector / every bias = -1), or None when the ranges do not tile the
+        buffer exactly (then the norm is always the one-pass form)."""
+        if not hasattr(self, "_norm_plan_cache"):
+            plan = None
+            try:
+                from mafed_amd.dist import layer_ranges
+                per_layer, head, tail = layer_ranges(self.model)
+                L = len(per_layer)
+                trig = {L: [head], -1: list(tail)}
+                for i, r in enumerate(per_layer):
+                    trig[i] = [r]
+                flat = sorted(r for rs in trig.values() for r in rs)
+                ok = flat[0][0] == 0 and flat[-1][1] == self.model.flat_grads.numel() and all(a[1] == b[0] for a, b in zip(flat, flat[1:]))
+                ok = ok and all(lo % 4 == 0 for lo, _ in flat)
+                if ok:
+                    plan, slot = {}, 0
+                    for t in [L] + list(range(L - 1, -1, -1)) + [-1]:
+                        plan[t] = []
+                        for lo, hi in trig[t]:
+                            plan[t].append((lo, hi, slot))
+                            slot += ops.gradnorm_blocks(hi - lo)
+                    self._norm_slots = slot
+                    self._norm_partials = torch.zeros(slot, dtype=torch.float32, device=self.model.flat_grads.device)
+            except Exception:
+                plan = None
+            self._norm_plan_cache = plan
+        return self._norm_plan_cache
+
+    def begin_incremental_norm(self):
+        """-> hook(i) for ``model.grad_ready_hook`` (or None): called by the backward on the stream that finished range i, it
+        launches that range's sum-of-squares partials at once -- under the rest of the backward -- so that ``clip_grad_norm_`` only
+        has the finish kernel left (the one-pass norm reads 1.6 GB on the optimiser step's critical path: 0.28 ms at 410M)."""
+        plan = self._norm_plan()
+        self._norm_seen = {}
+        if plan is None:
+            return None
+        g, part, model = self.model.flat_grads, self._norm_partials, self.model
+
+        def hook(i):
+            for lo, hi, slot in plan.get(i, ()):
+                ops.gradnorm_partial(g[lo:hi], part[slot:])
+            self._norm_seen[i] = getattr(model, "_bw_serial", 0)   # which backward sweep this range's partials belong to
+        return hook
+
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
-        """Global L2 norm + clip scale on the device; the scale is applied inside the AdamW kernel."""
-        ops.gradnorm_clip(self.model.flat_grads, max_norm, self.clip_out)
+        """Global L2 norm + clip scale on the device; the scale is applied inside the AdamW kernel.  Uses the partials left by the
+        backward's hooks when every range reported in this backward, the single pass otherwise."""
+        plan = getattr(self, "_norm_plan_cache", None)
+        seen = getattr(self, "_norm_seen", None)
+        last = getattr(self.model, "_bw_serial", 0)
+        # complete = every range reported during the LAST backward sweep (a sweep that skipped layers, or a plugin's extra sweep
+        # before it, leaves older partials behind: then the buffer is read in one pass as before)
+        if plan is not None and seen is not None and len(seen) == len(plan) and all(v == last for v in seen.values()):
+            ops.gradnorm_finish(self._norm_partials, max_norm, self.clip_out)
+        else:
+            ops.gradnorm_clip(self.model.flat_grads, max_norm, self.clip_out)
+        self._norm_seen = None
         self._clip_pending = True
         return self.clip_out[0]
 

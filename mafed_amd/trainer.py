@@ -23,7 +23,7 @@ from mafed_amd.optim import FlatAdamW, compute_warmup, get_linear_schedule_with_
 class Trainer:
     def __init__(self, model, cl_method, config: Optional[Any] = None, task_id: int = 0, n_batches_per_epoch: int = 1000,
                  process_group=None, ddp: bool = False, bucket_mb: float = 64.0, pipeline_optimizer: bool = False,
-                 grad_dtype: Optional[torch.dtype] = None, reduce_mode: str = "all_reduce"):
+                 grad_dtype: Optional[torch.dtype] = None, reduce_mode: str = "all_reduce", incremental_norm: bool = True):
         cfg = config if config is not None else SimpleNamespace()
         self.config = cfg
         self.model = model
@@ -47,6 +47,9 @@ class Trainer:
         # model's forward, or after join().
         self.pipeline_optimizer = bool(pipeline_optimizer) and torch.cuda.is_available()
         self._opt_stream = torch.cuda.Stream(device=model.flat_params.device) if self.pipeline_optimizer else None
+        # global-norm clip from per-range partials launched by the backward as each range becomes final (single process only: under
+        # DDP the gradient hook belongs to the reducer; plugins that touch gradients outside the model's backward keep the one-pass norm)
+        self.incremental_norm = bool(incremental_norm)
         self.global_step = 0
         self.optimizer.zero_grad()
         self.on_train_start()
@@ -83,6 +86,11 @@ class Trainer:
             self.reducer.enabled = window_end  # the gradient mean runs only on the last micro-batch of an accumulation window
             if window_end:
                 self.reducer.begin_window()
+        inc_norm = (window_end and self.reducer is None and self.grad_norm and self.grad_norm > 0 and self.incremental_norm
+                    and getattr(self.cl_method, "grads_only_through_model", False) and hasattr(self.model, "grad_ready_hook")
+                    and self.model.flat_grads.is_cuda)
+        if self.reducer is None and hasattr(self.model, "grad_ready_hook"):
+            self.model.grad_ready_hook = self.optimizer.begin_incremental_norm() if inc_norm else None
         loss, branch = self._training_step(batch, is_replay)
         (loss / self.accumulate if self.accumulate != 1 else loss).backward()
         if torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):

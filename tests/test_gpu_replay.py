@@ -42,8 +42,21 @@ def _conf(lr=1e-3, accumulate=1):
 
 
 def _run(method, model, loader, n_steps, pipeline, task_batch):
-    from mafed_amd import Trainer
-    tr = Trainer(model, method, _conf(), task_id=1, pipeline_optimizer=pipeline)
+    """``pipeline`` = the bench configuration: pipelined optimiser AND the clip norm from per-range partials launched by the
+    backward's hooks; the comparison run uses the one-pass norm at the start of the optimiser step."""
+    from mafed_amd import Trainer, ops
+    tr = Trainer(model, method, _conf(), task_id=1, pipeline_optimizer=pipeline, incremental_norm=pipeline)
+    calls = {"finish": 0, "onepass": 0}
+    fin, one = ops.gradnorm_finish, ops.gradnorm_clip
+    ops.gradnorm_finish = lambda *a, **k: (calls.__setitem__("finish", calls["finish"] + 1), fin(*a, **k))[1]
+    ops.gradnorm_clip = lambda *a, **k: (calls.__setitem__("onepass", calls["onepass"] + 1), one(*a, **k))[1]
+    try:
+        return _run_steps(tr, method, model, loader, n_steps, task_batch, calls, pipeline)
+    finally:
+        ops.gradnorm_finish, ops.gradnorm_clip = fin, one
+
+
+def _run_steps(tr, method, model, loader, n_steps, task_batch, calls, incremental):
     losses, gns = [], []
     for i in range(n_steps):
         if isinstance(loader, list):
@@ -54,6 +67,7 @@ def _run(method, model, loader, n_steps, pipeline, task_batch):
         gns.append(rec["grad_norm"])
     tr.join()
     torch.cuda.synchronize()
+    assert calls == ({"finish": n_steps, "onepass": 0} if incremental else {"finish": 0, "onepass": n_steps}), calls
     return [float(x) for x in losses], [float(x) for x in gns], model.flat_params.clone()
 
 

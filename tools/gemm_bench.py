@@ -46,7 +46,9 @@ for name, tA, tB, m, n, k, od in SHAPES:
     if EPI and name.startswith("fc1"):
         kw = dict(bias=torch.randn(n, device=dev), epilogue=ops.EPI_GELU, aux=torch.empty((m, n), dtype=od, device=dev))
     elif EPI and name.startswith("dfc2"):
-        kw = dict(epilogue=ops.EPI_GELU_BWD, aux=torch.randn((m, n), device=dev).to(od), colsum=torch.zeros(n, device=dev))
+        kw = dict(epilogue=ops.EPI_GELU_BWD, aux=torch.randn((m, n), device=dev).to(od))
+        if os.environ.get("GEMM_BENCH_NOCOLSUM", "0") != "1":
+            kw["colsum"] = torch.zeros(n, device=dev)
     elif EPI and name.startswith("fc2"):
         kw = dict(bias=torch.randn(n, device=dev), res1=torch.randn((m, n), device=dev).to(torch.bfloat16), res2=torch.randn((m, n), device=dev))
     for v in variants:
