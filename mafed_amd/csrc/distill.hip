@@ -9,16 +9,31 @@ namespace mafed {
 
 constexpr int DS_MAX_BLOCKS = 1024;
 
+// Row sums over h columns, 1024 columns (4 x 16 B per lane and tensor) per step: the eight loads of a step are unconditional
+// (columns past h re-read column 0 and are masked out afterwards) so that they are all in flight together -- a `c < h` loop with one
+// load pair per trip ran as h / 256 dependent round trips per row.
 __device__ __forceinline__ void row_stats(const float* __restrict__ s, const float* __restrict__ t, int h, int lane, float& dd,
                                           float& ss, float& tt, float& st) {
   dd = ss = tt = st = 0.f;
-  for (int c = lane * 4; c < h; c += 256) {
-    const float4 a = load4(s + c), b = load4(t + c);
-    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-    dd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    ss += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-    tt += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
-    st += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  for (int c0 = 0; c0 < h; c0 += 1024) {
+    float4 a[4], b[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + lane * 4 + 256 * u;
+      in[u] = c < h;
+      a[u] = load4(s + (in[u] ? c : 0));
+      b[u] = load4(t + (in[u] ? c : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float m = in[u] ? 1.f : 0.f;
+      const float d0 = a[u].x - b[u].x, d1 = a[u].y - b[u].y, d2 = a[u].z - b[u].z, d3 = a[u].w - b[u].w;
+      dd += m * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      ss += m * ((a[u].x * a[u].x + a[u].y * a[u].y) + (a[u].z * a[u].z + a[u].w * a[u].w));
+      tt += m * ((b[u].x * b[u].x + b[u].y * b[u].y) + (b[u].z * b[u].z + b[u].w * b[u].w));
+      st += m * ((a[u].x * b[u].x + a[u].y * b[u].y) + (a[u].z * b[u].z + a[u].w * b[u].w));
+    }
   }
 }
 
@@ -36,10 +51,15 @@ __global__ __launch_bounds__(256) void distill_fwd_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // lang_sum, vision_sum, n_lang, n_vision
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int cls = modality_class(row, S, P, T, attention_mask);
-    if (cls == 2) continue;
+    // mask word and row fetched together (the class decides afterwards whether the row counts): pad rows cost their loads, but a
+    // row no longer waits for its mask word first
+    const int64_t bi = row / S;
+    const int si = (int)(row - bi * S);
+    const int64_t mv = attention_mask[bi * T + (si < P ? 0 : si - P)];
     float dd, ss, tt, st;
     row_stats(s + row * h, t + row * h, h, lane, dd, ss, tt, st);
+    const int cls = si < P ? 1 : (mv != 0 ? 0 : 2);
+    if (cls == 2) continue;
     float d;
     if (COSINE) {
       ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
