@@ -609,265 +609,6 @@ static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int6
   return MAFED_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// LDS-DMA ring kernel: BK = 32 K-tiles in an NS-deep LDS ring, NS-1 tiles of DMA in flight behind a COUNTED
-// s_waitcnt vmcnt (never drained in the steady state) and a raw s_barrier, one barrier per K-tile (cdna_hip_programming
-// "Pipelining across barriers", T3+T4).  The 2-stage kernel above has exactly one K-tile of MFMAs to hide a DMA whose
-// latency under a chip-wide stream is several thousand cycles; the ring gives it NS-2 more.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int RK = 32;  // ring K-tile
-// KC image for 32-wide tiles: [rows][32 k], 64-byte rows (4 rows per 256-byte bank row), chunk ^ f(row>>2), f = {0,3,2,1}:
-// the 16 (row, chunk) pairs of every ds_read_b128 lane group land in 16 distinct 16-byte slots.
-__device__ __forceinline__ int ring_kc_f(int row) { return (0x6C >> (((row >> 2) & 3) * 2)) & 3; }  // {0,3,2,1} packed as 0b01101100
-__device__ __forceinline__ int ring_off_kc(int row, int chunk) { return row * 64 + ((chunk ^ ring_kc_f(row)) << 4); }
-
-template <bool KS, int R>
-__device__ __forceinline__ int64_t ring_src_off(int j, int lane, int64_t ld, int64_t r0) {
-  if (!KS) {
-    const int row = j * 16 + (lane >> 2), phys = lane & 3;
-    return (r0 + row) * ld + ((phys ^ ring_kc_f(row)) << 3);
-  } else {
-    constexpr int RB = 2 * R;
-    const int p = j * 1024 + lane * 16;
-    const int k = p / RB, within = p % RB;
-    const int logical16 = (within >> 5) ^ ks_f(k);
-    return (int64_t)k * ld + r0 + logical16 * 16 + ((within >> 4) & 1) * 8;
-  }
-}
-
-template <bool KS, int R>
-__device__ __forceinline__ bf16x8 ring_read_frag(const char* __restrict__ img, int rt, int lane) {
-  if (!KS) {
-    return *reinterpret_cast<const bf16x8*>(img + ring_off_kc(rt * 16 + (lane & 15), lane >> 4));
-  } else {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int ka = 8 * g + q, kb = ka + 4;
-    typedef __attribute__((address_space(3))) bf16x4* lptr;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks_r<R>(ka, rt, p * 8)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(img + lds_off_ks_r<R>(kb, rt, p * 8)));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int WM, int WN, int MT, int NT, int NS, bool A_KS, bool B_KS, typename CT>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_ring_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
-                                                                       int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                                       CT* __restrict__ C, GemmEpi epi, int tiles_n, int nwg) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, NW = WM * WN;
-  constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_PER_WAVE = TM / 16 / NW, B_PER_WAVE = TN / 16 / NW;  // 1 KiB DMA instructions per wave per K-tile
-  constexpr int LPT = A_PER_WAVE + B_PER_WAVE;                        // DMA instructions per wave per K-tile
-  static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && (TM / 16) % NW == 0 && (TN / 16) % NW == 0, "tile / wave count mismatch");
-  static_assert(NS >= 2 && LPT * (NS - 2) <= 63, "ring depth out of range for a counted vmcnt");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int64_t m0 = (int64_t)(bid / tiles_n) * TM, n0 = (int64_t)(bid % tiles_n) * TN;
-
-  const bf16_t* asrc[A_PER_WAVE];
-  const bf16_t* bsrc[B_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] = A + ring_src_off<A_KS, TM>(wave * A_PER_WAVE + i, lane, lda, m0);
-#pragma unroll
-  for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] = B + ring_src_off<B_KS, TN>(wave * B_PER_WAVE + i, lane, ldb, n0);
-  const int64_t a_step = A_KS ? RK * lda : RK, b_step = B_KS ? RK * ldb : RK;
-
-  auto issue = [&](int stage, int kt) {
-    char* sa = smem + stage * STAGE;
-    char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[i] + kt * a_step), (lds_void_ptr)(sa + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + kt * b_step), (lds_void_ptr)(sb + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0);
-  };
-
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = (int)(K / RK);
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nkt) issue(s, s);
-  int stage = 0;  // stage of tile kt
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tile kt must have landed; in the steady state NS-2 younger tiles stay in flight across the barrier
-    if (kt + NS - 2 < nkt) wait_vmcnt<LPT*(NS - 2)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int nt_issue = kt + NS - 1;
-      int st = stage - 1;
-      if (st < 0) st += NS;  // the stage tile kt-1 lived in: free now
-      if (nt_issue < nkt) issue(st, nt_issue);
-    }
-    const char* sa = smem + stage * STAGE;
-    const char* sb = sa + A_BYTES;
-    bf16x8 fa[MT], fb[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) fb[t] = ring_read_frag<B_KS, TN>(sb, wn * NT + t, lane);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) fa[t] = ring_read_frag<A_KS, TM>(sa, wm * MT + t, lane);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-    stage = stage + 1 == NS ? 0 : stage + 1;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int64_t m = m0 + (wm * MT + mt) * 16 + (lane & 15);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int64_t n = n0 + (wn * NT + nt) * 16 + 4 * (lane >> 4);
-      epilogue_store4<CT, true>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
-    }
-  }
-}
-
-template <int WM, int WN, int MT, int NT, int NS, bool A_KS, bool B_KS, typename CT>
-static int launch_bf16_ring(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
-                            const GemmEpi& epi, hipStream_t st) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, LDS = NS * (TM + TN) * 64;
-  const int64_t tm = M / TM, tn = N / TN, nwg = tm * tn;
-  if (nwg > 0x7fffffff) { set_error("gemm: grid too large"); return MAFED_EINVAL; }
-  auto kfn = gemm_bf16_ring_kernel<WM, WN, MT, NT, NS, A_KS, B_KS, CT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  kfn<<<dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi, (int)tn,
-                                                             (int)nwg);
-  return MAFED_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// LDS-DMA kernel with register-level software pipelining of the fragment reads: the ds_reads of k-step p+1 are in
-// flight under the MFMAs of k-step p (two fragment register sets), so a wave no longer parks on lgkmcnt before every
-// MFMA batch (SQ_WAIT_ANY was 39-44 % of wave cycles in the un-pipelined kernel, with zero bank conflicts).
-// Per K-tile kt, between two barriers:   DMA(kt+1) ; F0 <- frags(kt, ks0) ; MFMA(F1 = kt-1, ks1) ;
-//                                        F1 <- frags(kt, ks1) ; MFMA(F0) ; vmcnt(0) + barrier
-// Tile kt+1's DMA still has one full K-tile of MFMAs to land; its target stage was last read before the barrier.
-// ------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_pipe_kernel(int64_t M, int64_t N, int64_t K, const bf16_t* __restrict__ A,
-                                                                       int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                                       CT* __restrict__ C, GemmEpi epi, int tiles_n, int nwg) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, NW = WM * WN;
-  constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_PER_WAVE = TM / 8 / NW, B_PER_WAVE = TN / 8 / NW;
-  static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && (TM / 8) % NW == 0 && (TN / 8) % NW == 0, "tile / wave count mismatch");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int64_t m0 = (int64_t)(bid / tiles_n) * TM, n0 = (int64_t)(bid % tiles_n) * TN;
-
-  const bf16_t* asrc[A_PER_WAVE];
-  const bf16_t* bsrc[B_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < A_PER_WAVE; ++i) asrc[i] = A + glds_src_off<A_KS, TM>(wave * A_PER_WAVE + i, lane, lda, m0);
-#pragma unroll
-  for (int i = 0; i < B_PER_WAVE; ++i) bsrc[i] = B + glds_src_off<B_KS, TN>(wave * B_PER_WAVE + i, lane, ldb, n0);
-  const int64_t a_step = A_KS ? 64 * lda : 64, b_step = B_KS ? 64 * ldb : 64;
-
-  auto issue = [&](int stage, int kt) {
-    char* sa = smem + stage * STAGE;
-    char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[i] + kt * a_step), (lds_void_ptr)(sa + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + kt * b_step), (lds_void_ptr)(sb + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0);
-  };
-
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-
-#define MAFED_READ_FRAGS(FA, FB, SA, SB, KS)                                                     \
-  _Pragma("unroll") for (int t = 0; t < NT; ++t) FB[t] = glds_read_frag<B_KS, TN>(SB, wn * NT + t, KS, lane); \
-  _Pragma("unroll") for (int t = 0; t < MT; ++t) FA[t] = glds_read_frag<A_KS, TM>(SA, wm * MT + t, KS, lane);
-#define MAFED_MFMAS(FA, FB)                                                                       \
-  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
-  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                               \
-      acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt], FA[mt], acc[nt][mt], 0, 0, 0);
-
-  const int nkt = (int)(K / BK);
-  issue(0, 0);
-  __syncthreads();  // tile 0 landed
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* sa = smem + (kt & 1) * STAGE;
-    const char* sb = sa + A_BYTES;
-    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);  // its stage held tile kt-1: every wave read it before the last barrier
-    MAFED_READ_FRAGS(fa0, fb0, sa, sb, 0)
-    if (kt > 0) { MAFED_MFMAS(fa1, fb1) }            // (kt-1, ks1) under the reads of (kt, ks0)
-    __builtin_amdgcn_sched_barrier(0);
-    MAFED_READ_FRAGS(fa1, fb1, sa, sb, 1)
-    MAFED_MFMAS(fa0, fb0)                            // (kt, ks0) under the reads of (kt, ks1)
-    __syncthreads();                                 // vmcnt(0): tile kt+1 landed; all reads of tile kt are complete
-  }
-  MAFED_MFMAS(fa1, fb1)
-#undef MAFED_READ_FRAGS
-#undef MAFED_MFMAS
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int64_t m = m0 + (wm * MT + mt) * 16 + (lane & 15);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int64_t n = n0 + (wn * NT + nt) * 16 + 4 * (lane >> 4);
-      epilogue_store4<CT, true>(epi, C, m, n, make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]));
-    }
-  }
-}
-
-template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT>
-static int launch_bf16_pipe(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
-                            const GemmEpi& epi, hipStream_t st) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, LDS = 2 * (TM + TN) * 128;
-  const int64_t tm = M / TM, tn = N / TN, nwg = tm * tn;
-  if (nwg > 0x7fffffff) { set_error("gemm: grid too large"); return MAFED_EINVAL; }
-  auto kfn = gemm_bf16_pipe_kernel<WM, WN, MT, NT, A_KS, B_KS, CT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  kfn<<<dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, st>>>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, epi, (int)tn,
-                                                             (int)nwg);
-  return MAFED_OK;
-}
-
 // tile configurations of the LDS-DMA kernel: 0 = 128x128 (4 waves of 64x64, 2 blocks/CU), 1 = 256x256 (8 waves of 128x64,
 // 1 block/CU: one K-tile of MFMAs per SIMD then covers the DMA latency), 2 = 256x128 (8 waves of 64x64)
 template <bool A_KS, bool B_KS, typename CT>
@@ -876,10 +617,6 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
   switch (cfg) {
     case 1: return launch_bf16_glds<2, 4, 8, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);
     case 2: return launch_bf16_glds<4, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);
-    case 3: return launch_bf16_ring<2, 2, 4, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 128x128, ring of 4 (64 KiB)
-    case 4: return launch_bf16_ring<2, 4, 8, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 256x256, ring of 4 (128 KiB)
-    case 5: return launch_bf16_ring<2, 4, 8, 4, 5, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 256x256, ring of 5 (160 KiB)
-    case 6: return launch_bf16_ring<2, 2, 4, 4, 5, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 128x128, ring of 5 (80 KiB)
     case 11: if constexpr (!A_KS) return launch_bf16_glds<1, 4, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 4 waves of 144x32
     case 12: if constexpr (!A_KS) return launch_bf16_glds<3, 2, 3, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, 6 waves of 48x64
     case 13: if constexpr (!A_KS) return launch_bf16_glds<1, 8, 9, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x256, 8 waves of 144x32
@@ -897,10 +634,6 @@ static int launch_bf16_glds_cfg(int cfg, int64_t M, int64_t N, int64_t K, const 
     case 29: return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT, 7>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x128, epilogue only (timing)
     case 30: if constexpr (!A_KS) return launch_bf16_glds<1, 4, 9, 2, A_KS, B_KS, CT, 7>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 144x128, epilogue only (timing)
     case 27: if constexpr (!A_KS) return launch_bf16_glds<2, 2, 6, 4, A_KS, B_KS, CT, 7>(M, N, K, A, lda, B, ldb, C, epi, st); else break;  // 192x128, epilogue only (timing)
-    case 9: return launch_bf16_ring<2, 2, 4, 4, 2, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);   // 128x128, BK 32, 2 stages (32 KiB): 4 blocks / CU
-    case 10: return launch_bf16_ring<2, 2, 4, 4, 3, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);  // 128x128, BK 32, 3 stages (48 KiB): 3 blocks / CU
-    case 7: return launch_bf16_pipe<2, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);      // 128x128, pipelined fragment reads
-    case 8: return launch_bf16_pipe<2, 4, 8, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);      // 256x256, pipelined fragment reads
     default: break;
   }
   return launch_bf16_glds<2, 2, 4, 4, A_KS, B_KS, CT>(M, N, K, A, lda, B, ldb, C, epi, st);
@@ -1020,7 +753,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
       else if (want == 18 && ok128 && c_dtype == MAFED_F32 && !colsum && (K / 64) % 2 == 0) cfg = 18;
       else if (want == 29 && ok128) cfg = 29;
       else if (want == 30 && ok144) cfg = 30;
-      else if (((want == 0 || want == 3 || want == 6 || want == 7 || want == 9 || want == 10 || (want >= 21 && want <= 26)) && ok128) || ((want == 1 || want == 4 || want == 5 || want == 8) && ok256) || (want == 2 && ok256x128)) cfg = want;
+      else if (((want == 0 || (want >= 21 && want <= 26)) && ok128) || (want == 1 && ok256) || (want == 2 && ok256x128)) cfg = want;
       else if (ok128) cfg = 0;
     } else {
       // automatic: 128x128 tiles, unless 144-row tiles fill the 512 resident blocks much better (M = 9216 with N = 1024:

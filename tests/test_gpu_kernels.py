@@ -61,9 +61,10 @@ GEMM_SHAPES = [(128, 128, 64), (48, 136, 72), (264, 392, 200), (16, 8, 8), (1024
 # variants on the product path: 0 automatic dispatch, 1 register-staged kernel (ragged shapes), 21 / 27 the 144x128 and 192x128
 # LDS-DMA tiles the dispatcher picks for M = 9216 -- the full shape x transpose matrix.  The measured-and-kept-for-reference tile
 # configurations behind mafed_gemm_set_variant get ONE qualifying shape each (all four transpose modes).
+# variant = 10 + tile configuration (mafed_gemm_set_variant): 11 256x256, 12 256x128, 21 144x128, 22 144x128 (6 waves), 23 144x256,
+# 24 128x64, 25 64x128, 26 288x256, 27 192x128, 28 128x128 with two K groups
 GEMM_CASES = [(v, s) for v in (0, 1, 21, 27) for s in GEMM_SHAPES] + [
-    (11, (512, 768, 320)), (12, (512, 768, 320)), (13, (384, 640, 192)), (14, (512, 768, 320)), (15, (512, 768, 320)), (16, (384, 640, 192)),
-    (17, (384, 640, 192)), (18, (512, 768, 320)), (22, (576, 384, 128)), (23, (576, 768, 256)), (24, (384, 640, 192)), (25, (384, 640, 192)),
+    (11, (512, 768, 320)), (12, (512, 768, 320)), (22, (576, 384, 128)), (23, (576, 768, 256)), (24, (384, 640, 192)), (25, (384, 640, 192)),
     (26, (576, 768, 256)), (28, (512, 768, 384)), (28, (256, 128, 1152))]
 
 
