@@ -455,23 +455,25 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
       }
     }
     if (epi.colsum) colsum_flush_block<8, TN>(cs, reinterpret_cast<float*>(smem), epi.colsum, n0, wn * 64, lane, tid);
-  } else if constexpr (MT == 6 && NT == 4 && STAGE * 2 >= NW * 12288) {
-    // 96 x 64 wave tile (192 x 128 block): two passes of 3 row tiles through a wave-private 48 x 64 fp32 region
+  } else if constexpr ((MT == 3 || MT == 6 || MT == 9) && NT == 4) {
+    // 48 / 96 / 144 x 64 wave tiles (144 x 128 with six waves, 192 x 128, 288 x 256): MT / 3 passes of 3 row tiles through a
+    // wave-private 48 x 64 fp32 region (the launcher sizes the dynamic LDS for it when the operand stages are smaller)
+    constexpr int NPASS = MT / 3;
     __syncthreads();
     float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bv[8];
     epi_bias8(epi, n0 + wn * 64 + 8 * (lane & 7), bv);
-    EpiPre pre[2][6];  // bf16 slot only: pass 1's operands are requested before pass 0's stores go out
+    EpiPre pre[2][6];  // bf16 slot only, ping-pong: pass p + 1's operands are requested before pass p's stores go out
 #pragma unroll
     for (int it = 0; it < 6; ++it)
-      epi_prefetch<CT, false>(epi, C, m0 + (wm * 6) * 16 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[0][it]);
+      epi_prefetch<CT, false>(epi, C, m0 + (wm * MT) * 16 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[0][it]);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 0) {
+    for (int pass = 0; pass < NPASS; ++pass) {
+      if (pass + 1 < NPASS) {
 #pragma unroll
         for (int it = 0; it < 6; ++it)
-          epi_prefetch<CT, false>(epi, C, m0 + (wm * 6 + 3) * 16 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[1][it]);
+          epi_prefetch<CT, false>(epi, C, m0 + (wm * MT + (pass + 1) * 3) * 16 + it * 8 + (lane >> 3), n0 + wn * 64 + 8 * (lane & 7), pre[(pass + 1) & 1][it]);
       }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -489,39 +491,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_bf16_glds_kernel(int64
         const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        epilogue_store8_pre<CT, false>(epi, C, m0 + (wm * 6 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v, pre[pass][it], bv);
-        if (epi.colsum) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) cs[i] += v[i];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (epi.colsum) colsum_flush_block<8, TN>(cs, reinterpret_cast<float*>(smem), epi.colsum, n0, wn * 64, lane, tid);
-  } else if constexpr (MT == 9 && NT == 4 && STAGE * 2 >= NW * 12288) {
-    // 144 x 64 wave tile (288 x 256 block): three passes of 3 row tiles through a wave-private 48 x 64 fp32 region
-    __syncthreads();
-    float* reg = reinterpret_cast<float*>(smem) + wave * 3072;
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int row = t * 16 + (lane & 15);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int c4 = (nt * 4 + (lane >> 4)) ^ (row & 15);
-          *reinterpret_cast<f32x4*>(reg + row * 64 + c4 * 4) = acc[nt][pass * 3 + t];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        const int row = it * 8 + (lane >> 3), j = lane & 7;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j) ^ (row & 15)) << 2));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 64 + (((2 * j + 1) ^ (row & 15)) << 2));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        epilogue_store8<CT>(epi, C, m0 + (wm * 9 + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v);
+        epilogue_store8_pre<CT, false>(epi, C, m0 + (wm * MT + pass * 3) * 16 + row, n0 + wn * 64 + 8 * j, v, pre[pass & 1][it], bv);
         if (epi.colsum) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) cs[i] += v[i];
@@ -593,7 +563,10 @@ static int g_gemm_nsplit = 1;  // set by the dispatcher for the next launch_bf16
 template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT, int ABL = 0, int KG = 1>
 static int launch_bf16_glds(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                             const GemmEpi& epi, hipStream_t st) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, LDS = KG * 2 * (TM + TN) * 128;
+  constexpr int TM = WM * MT * 16, TN = WN * NT * 16, STAGES = KG * 2 * (TM + TN) * 128;
+  // the staged epilogue of the 3 / 6 / 9-row-tile waves needs 12 KiB per wave: more than the operand stages of the six-wave 144 x 128 tile
+  constexpr int EPI_LDS = ((MT == 3 || MT == 6 || MT == 9) && NT == 4) ? WM * WN * 12288 : 0;
+  constexpr int LDS = STAGES > EPI_LDS ? STAGES : EPI_LDS;
   const int64_t tm = M / TM, tn = N / TN, nwg = tm * tn;
   if (nwg > 0x7fffffff) { set_error("gemm: grid too large"); return MAFED_EINVAL; }
   auto kfn = gemm_bf16_glds_kernel<WM, WN, MT, NT, A_KS, B_KS, CT, ABL, KG>;
@@ -763,6 +736,9 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
         auto eff = [](int64_t t) { return (double)t / (double)(((t + 511) / 512) * 512); };
         const double e144 = eff((M / 144) * (N / 128)), e128 = ok128 ? eff((M / 128) * (N / 128)) : 0.0;
         if (e144 >= e128) cfg = 11;
+        // at most one 144 x 128 tile per CU (M = 4608 = 16 x 288 rows with N = 1024: 256 tiles): six waves of 48 x 64 instead of four of
+        // 144 x 32 keep a lone block's SIMDs busier -- dense 18.9 vs 22.5 us, fc2 48.8 vs 56.2, dX of fc1 47.9 vs 56.5 (vs 128 x 128)
+        if ((M / 144) * (N / 128) <= 256) cfg = 12;
         // 192 x 128 tiles (96 x 64 per wave: 31 % fewer LDS fragment reads and 22 % fewer DMA pieces per MFMA, still two
         // blocks per CU) when they fill the 512 slots in whole rounds: the N = 4096 GEMMs (1536 tiles); 895-917 vs 840-856
         if ((M % 192 == 0) && (((M / 192) * (N / 128)) % 512 == 0)) cfg = 17;
@@ -787,7 +763,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     g_gemm_nsplit = ns;
   }
   if (cfg >= 0) {
-    const bool fused_colsum = colsum && g_gemm_nsplit == 1 && (cfg == 0 || cfg == 11 || cfg == 16 || cfg == 17);
+    const bool fused_colsum = colsum && g_gemm_nsplit == 1 && (cfg == 0 || cfg == 11 || cfg == 12 || cfg == 16 || cfg == 17);
     if (fused_colsum) epi.colsum = colsum;
 #define GOG(AKS, BKS)                                                                                                       \
   rc = (c_dtype == MAFED_F32) ? launch_bf16_glds_cfg<AKS, BKS, float>(cfg, M, N, K, A, lda, B, ldb, C, epi, st)             \

@@ -7,7 +7,7 @@ import torch
 from mafed_amd import ops, _lib
 
 dev = "cuda"
-M = 9216
+M = int(os.environ.get("GEMM_BENCH_M", "9216"))   # rows = batch x (image + text tokens): 9216 = 32 x 288, 4608 = 16 x 288
 SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
     ("qkv   NT", False, True, M, 3072, 1024, torch.bfloat16),
     ("dense NT", False, True, M, 1024, 1024, torch.float32),
