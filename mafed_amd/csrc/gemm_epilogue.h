@@ -50,6 +50,33 @@ __device__ __forceinline__ void epilogue_store4(const GemmEpi& e, CT* __restrict
   store4(C + off, v);
 }
 
+// epilogue_store4 with the bias / residual operands already in registers (epi_fetch4, issued before the product's main loop):
+// behind the cross-wave fold of the skinny kernel each of them was a dependent round trip (bias, res1, res2 per 16-row tile: the
+// 4h -> h projection of a decode step spent more time there than streaming its 8 MB of weights).  No beta, no GELU' (not on that path).
+struct EpiPre4 {
+  float4 b, r1, r2;
+};
+__device__ __forceinline__ void epi_fetch4(const GemmEpi& e, int64_t m, int64_t n, EpiPre4& p) {
+  const int64_t off = m * e.ldc + n;
+  p.b = e.bias ? load4(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  p.r1 = e.res1 ? (e.res1_bf16 ? load4(reinterpret_cast<const bf16_t*>(e.res1) + off) : load4(e.res1 + off)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  p.r2 = e.res2 ? load4(e.res2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <typename CT>
+__device__ __forceinline__ void epilogue_store4_pre(const GemmEpi& e, CT* __restrict__ C, int64_t m, int64_t n, float4 v, const EpiPre4& p) {
+  const int64_t off = m * e.ldc + n;
+  v.x += p.b.x; v.y += p.b.y; v.z += p.b.z; v.w += p.b.w;
+  if (e.mode == MAFED_EPI_GELU) {
+    if (e.aux) store4(reinterpret_cast<CT*>(e.aux) + off, v);
+    v = make_float4(gelu_erf_fast(v.x), gelu_erf_fast(v.y), gelu_erf_fast(v.z), gelu_erf_fast(v.w));
+  } else if (e.mode == MAFED_EPI_QUICK_GELU) {
+    v = make_float4(quick_gelu(v.x), quick_gelu(v.y), quick_gelu(v.z), quick_gelu(v.w));
+  }
+  v.x += p.r1.x; v.y += p.r1.y; v.z += p.r1.z; v.w += p.r1.w;   // same order of additions as epilogue_store4
+  v.x += p.r2.x; v.y += p.r2.y; v.z += p.r2.z; v.w += p.r2.w;
+  store4(C + off, v);
+}
+
 // 8 consecutive columns n..n+7 of row m (n % 8 == 0): the coalesced form used after the accumulators went through LDS
 // (16-byte bf16 / 32-byte fp32 stores, 128/256 contiguous bytes per row per 8 lanes).
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {

@@ -31,6 +31,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(int M, int64_t 
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the storing wave requests its bias / residual operands now: they arrive under the weight stream
+  EpiPre4 epre[MT];
+  if (wave == 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + i;
+      epi_fetch4(epi, m < M ? m : 0, n0 + (4 * g < NS ? 4 * g : 0), epre[mt]);
+    }
+  }
   const bf16x8 zero = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
   int64_t k = 0;
   for (; k + 128 <= kper; k += 128) {  // four k-steps per trip: every load of the trip is in flight before the first MFMA
@@ -67,7 +76,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(int M, int64_t 
       for (int w = 0; w < NW - 1; ++w) a += red[w][mt][lane];
       // lane holds C[m = mt*16 + (lane & 15)][n0 + 4g .. 4g+3]
       const int m = mt * 16 + i;
-      if (m < M && 4 * g < NS) epilogue_store4<CT, true>(epi, C, m, n0 + 4 * g, make_float4(a[0], a[1], a[2], a[3]));
+      if (m < M && 4 * g < NS) {
+        if (epi.mode == MAFED_EPI_GELU_BWD) epilogue_store4<CT, true>(epi, C, m, n0 + 4 * g, make_float4(a[0], a[1], a[2], a[3]));
+        else epilogue_store4_pre<CT>(epi, C, m, n0 + 4 * g, make_float4(a[0], a[1], a[2], a[3]), epre[mt]);
+      }
     }
   }
 }
