@@ -29,7 +29,16 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """Raw handle of the caller's current HIP stream.  Through the two C entry points directly when this torch has them:
+    ``torch.cuda.current_stream()`` builds a Stream object and resolves the device index through ``is_available()`` on every call
+    (3 of the 15 ms the host spent enqueueing a 410M MAFED step, ~650 launches)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
