@@ -128,6 +128,7 @@ class FlatAdamW:
             for lo, hi, slot in plan.get(i, ()):
                 ops.gradnorm_partial(g[lo:hi], part[slot:])
             self._norm_seen[i] = getattr(model, "_bw_serial", 0)   # which backward sweep this range's partials belong to
+        hook.is_norm_hook = True   # Trainer replaces / removes hooks of this kind only
         return hook
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:

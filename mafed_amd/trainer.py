@@ -90,7 +90,11 @@ class Trainer:
                     and getattr(self.cl_method, "grads_only_through_model", False) and hasattr(self.model, "grad_ready_hook")
                     and self.model.flat_grads.is_cuda)
         if self.reducer is None and hasattr(self.model, "grad_ready_hook"):
-            self.model.grad_ready_hook = self.optimizer.begin_incremental_norm() if inc_norm else None
+            cur = self.model.grad_ready_hook
+            if cur is None or getattr(cur, "is_norm_hook", False):   # (a hook installed by somebody else is left alone)
+                self.model.grad_ready_hook = self.optimizer.begin_incremental_norm() if inc_norm else None
+            else:
+                self.optimizer._norm_seen = None
         loss, branch = self._training_step(batch, is_replay)
         (loss / self.accumulate if self.accumulate != 1 else loss).backward()
         if torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
