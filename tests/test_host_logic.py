@@ -213,3 +213,38 @@ def test_ewc_foreign_module_path_matches_oracle():
     ewc.update(model=m, dataloader=loader)   # task_id 2: new + 0.9 * old
     for k in f1:
         assert torch.allclose(ewc.fisher[0][k], f1[k] * 1.9, rtol=1e-5)
+
+
+def test_clip_norm_plan_tiles_the_gradient_buffer():
+    """FlatAdamW._norm_plan: the per-hook ranges of the incremental clip norm (LM head, layers L-1 .. 0, embeddings / projector / biases)
+    must tile the flat gradient buffer exactly once -- otherwise the norm would miss or double-count elements -- with 16-byte aligned
+    starts and consecutive partial slots."""
+    from mafed_amd import VLPythiaConfig, VLPythiaForCausalLM, ops
+    from mafed_amd.optim import FlatAdamW
+    for L, h in ((5, 32), (3, 64)):
+        cfg = VLPythiaConfig(vocab_size=64, hidden_size=h, num_hidden_layers=L, num_attention_heads=2, intermediate_size=4 * h,
+                             vision_hidden_size=16, num_vision_tokens=4)
+        model = VLPythiaForCausalLM(cfg, compute_dtype=torch.float32, device="cpu")
+        opt = FlatAdamW.__new__(FlatAdamW)     # no device state: only the plan is under test
+        opt.model = model
+        plan = opt._norm_plan()
+        assert plan is not None and sorted(plan) == [-1] + list(range(L)) + [L]
+        ranges = sorted((lo, hi, slot) for rs in plan.values() for lo, hi, slot in rs)
+        assert ranges[0][0] == 0 and ranges[-1][1] == model.flat_grads.numel()
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), "ranges must be contiguous and disjoint"
+        assert all(lo % 4 == 0 for lo, _, _ in ranges)
+        order = [r for t in [L] + list(range(L - 1, -1, -1)) + [-1] for r in plan[t]]
+        slot = 0
+        for lo, hi, s in order:
+            assert s == slot
+            slot += ops.gradnorm_blocks(hi - lo)
+        assert slot == opt._norm_slots == opt._norm_partials.numel()
+
+
+def test_clip_tower_row_padding_minimises_tile_rounds():
+    from mafed_amd.vision import _pad_rows
+    assert _pad_rows(32 * 257, (1024, 3072, 4096)) == 8352      # 58 x 144 rows: 1 + 3 + 4 rounds of 512 tiles (65 x 128: 2 + 4 + 5)
+    assert _pad_rows(8192, (1024, 3072, 4096)) == 8192          # already a multiple of 128 that fills whole rounds
+    for rows in (1, 100, 257, 5000):
+        p = _pad_rows(rows, (1024, 3072, 4096))
+        assert p >= rows and (p % 128 == 0 or p % 144 == 0)
