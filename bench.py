@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-image-leg", action="store_true", help="skip the image-input measurement (CLIP-ViT-L/14 tower in front of the step)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
+    ap.add_argument("--no-defer-ln", action="store_true", help="LayerNorm parameter reduction on the dX stream (A/B)")
     ap.add_argument("--no-incremental-norm", action="store_true", help="clip norm in one pass at the start of the optimiser step (A/B)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
     ap.add_argument("--reduce-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
@@ -189,6 +190,8 @@ def main():
     broadcast_teacher(fd.past_model)
     fd.task_id = 1
     fd.num_vision_tokens = P
+    if args.no_defer_ln:
+        student.defer_ln_param_reduce = False
     if args.no_overlap:
         student.overlap_param_grads = False
         fd.overlap_teacher = False

@@ -104,6 +104,16 @@ int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype,
                         const float* inj_scale_dev /* [2] device: {lang, vision} or NULL */, float inj_mul /* host factor, e.g. 2/h */,
                         float* dxsum_a, float* dxsum_b /* optional fp32 [h]: += column sums of dx (bias grads of the layer below) */,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward in two calls, so that the parameter reduction can run on another stream, off the dX chain (the caller orders
+ * it behind the row kernel and keeps `workspace` private to this pair):
+ *   mafed_layernorm_bwd_rows    dx, dx_lp and the per-block partials of dw / db (/ column sums of dx when want_dxsum) into workspace
+ *   mafed_layernorm_bwd_params  workspace -> dw1, db1 (dw2, db2), dxsum_a / dxsum_b; pass dw2 / dxsum_* exactly as "dual" / want_dxsum were */
+int mafed_layernorm_bwd_rows(const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean, const float* rstd,
+                             const float* w1, const float* w2, int64_t rows, int h, const float* dres, float* dx, void* dx_lp,
+                             const float* teacher, const int64_t* attention_mask, int S, int P, int T, const float* inj_scale_dev,
+                             float inj_mul, int want_dxsum, void* workspace, size_t workspace_bytes, void* stream);
+int mafed_layernorm_bwd_params(int64_t rows, int h, float* dw1, float* db1, float* dw2, float* db2, float* dxsum_a, float* dxsum_b,
+                               const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- attention (tf:154-236 eager path / flash-attn-2 wheel, README.md:16) ------------------------------------
  * qkv: [B,S,H,3,D] exactly as the fused query_key_value GEMM leaves it (per-head {q,k,v} interleave, tf:204-207).

@@ -33,6 +33,8 @@ SIGNATURES = {
     "mafed_layernorm_fwd": (_i, [_p, _l, _i, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
     "mafed_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _p, _p, _p, _z, _p]),
+    "mafed_layernorm_bwd_rows": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _i, _p, _z, _p]),
+    "mafed_layernorm_bwd_params": (_i, [_l, _i, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "mafed_attn_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_attn_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "mafed_attn_bwd_colsum": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),

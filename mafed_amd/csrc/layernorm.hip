@@ -297,12 +297,50 @@ extern "C" size_t mafed_layernorm_bwd_workspace_bytes(int64_t rows, int h) {
   return (size_t)ln_bwd_blocks(rows) * 5 * (size_t)h * sizeof(float);
 }
 
+// phase: 0 = both kernels on `stream`; 1 = the row kernel only (dx, dx_lp and the per-block parameter partials in `workspace`);
+// 2 = the parameter reduction only (workspace -> dw / db / dxsum, on `stream`: a side stream, off the dX chain)
+static int layernorm_bwd_impl(int phase, const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean,
+                              const float* rstd, const float* w1, const float* w2, int64_t rows, int h,
+                              const float* dres, float* dx, void* dx_lp, float* dw1, float* db1, float* dw2, float* db2,
+                              const float* teacher, const int64_t* attention_mask, int S, int P, int T,
+                              const float* inj_scale_dev, float inj_mul, float* dxsum_a, float* dxsum_b, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean,
                                    const float* rstd, const float* w1, const float* w2, int64_t rows, int h,
                                    const float* dres, float* dx, void* dx_lp, float* dw1, float* db1, float* dw2, float* db2,
                                    const float* teacher, const int64_t* attention_mask, int S, int P, int T,
                                    const float* inj_scale_dev, float inj_mul, float* dxsum_a, float* dxsum_b, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+  return layernorm_bwd_impl(0, dy1, dy2, dy_dtype, x, mean, rstd, w1, w2, rows, h, dres, dx, dx_lp, dw1, db1, dw2, db2, teacher, attention_mask, S, P,
+                            T, inj_scale_dev, inj_mul, dxsum_a, dxsum_b, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mafed_layernorm_bwd_rows(const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean,
+                                        const float* rstd, const float* w1, const float* w2, int64_t rows, int h, const float* dres, float* dx,
+                                        void* dx_lp, const float* teacher, const int64_t* attention_mask, int S, int P, int T,
+                                        const float* inj_scale_dev, float inj_mul, int want_dxsum, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  float dummy = 0.f;   // the row kernel never dereferences the parameter-gradient pointers: non-null stands for "wanted"
+  return layernorm_bwd_impl(1, dy1, dy2, dy_dtype, x, mean, rstd, w1, w2, rows, h, dres, dx, dx_lp, &dummy, &dummy, dy2 ? &dummy : nullptr,
+                            dy2 ? &dummy : nullptr, teacher, attention_mask, S, P, T, inj_scale_dev, inj_mul, want_dxsum ? &dummy : nullptr, nullptr,
+                            workspace, workspace_bytes, stream);
+}
+
+extern "C" int mafed_layernorm_bwd_params(int64_t rows, int h, float* dw1, float* db1, float* dw2, float* db2, float* dxsum_a, float* dxsum_b,
+                                          const void* workspace, size_t workspace_bytes, void* stream) {
+  float dummy = 0.f;   // operands of the row kernel: only tested for presence in this phase
+  return layernorm_bwd_impl(2, &dummy, dw2 ? &dummy : nullptr, MAFED_F32, &dummy, &dummy, &dummy, &dummy, dw2 ? &dummy : nullptr, rows, h, nullptr, &dummy,
+                            nullptr, dw1, db1, dw2, db2, nullptr, nullptr, 0, 0, 0, nullptr, 0.f, dxsum_a, dxsum_b, const_cast<void*>(workspace),
+                            workspace_bytes, stream);
+}
+
+static int layernorm_bwd_impl(int phase, const void* dy1, const void* dy2, mafed_dtype dy_dtype, const float* x, const float* mean,
+                              const float* rstd, const float* w1, const float* w2, int64_t rows, int h,
+                              const float* dres, float* dx, void* dx_lp, float* dw1, float* db1, float* dw2, float* db2,
+                              const float* teacher, const int64_t* attention_mask, int S, int P, int T,
+                              const float* inj_scale_dev, float inj_mul, float* dxsum_a, float* dxsum_b, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   MAFED_CHECK_ARG(dy1 && x && mean && rstd && w1 && dx && dw1 && db1, "layernorm_bwd: null pointer");
   MAFED_CHECK_ARG(h > 0 && h % 4 == 0, "layernorm_bwd: h=%d must be a positive multiple of 4", h);
   const bool dual = dy2 != nullptr;
@@ -343,17 +381,20 @@ extern "C" int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype
 #define DISPATCH_T(NV)                          \
   if (dy_dtype == MAFED_F32) { DISPATCH_D(NV, float); } \
   else { DISPATCH_D(NV, bf16_t); }
-  switch (nv) {
-    case 1: DISPATCH_T(1); break;
-    case 2: DISPATCH_T(2); break;
-    case 3: DISPATCH_T(3); break;
-    case 4: DISPATCH_T(4); break;
-    default: DISPATCH_T(8); break;
+  if (phase != 2) {
+    switch (nv) {
+      case 1: DISPATCH_T(1); break;
+      case 2: DISPATCH_T(2); break;
+      case 3: DISPATCH_T(3); break;
+      case 4: DISPATCH_T(4); break;
+      default: DISPATCH_T(8); break;
+    }
+    MAFED_CHECK_LAUNCH("layernorm_bwd");
   }
 #undef DISPATCH_T
 #undef DISPATCH_D
 #undef LAUNCH
-  MAFED_CHECK_LAUNCH("layernorm_bwd");
+  if (phase == 1) return MAFED_OK;
   const int tot = np * h;
   launch(K_LN_BWD_REDUCE, (double)nblk * np * h * 4.0, ln_param_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, partial, nblk, np, h, dw1,
          db1, dw2, db2, dxsum ? np - 1 : -1, dxsum_a, dxsum_b);

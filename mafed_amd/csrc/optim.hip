@@ -32,8 +32,19 @@ __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __re
 __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm,
                                                               float* __restrict__ out2) {
   __shared__ float sm[4];
-  float s = 0.f;
-  for (int b = threadIdx.x; b < nblk; b += 256) s += partial[b];
+  // eight loads in flight per thread (the piecewise norm leaves ~27k partials at 410M: one load per trip was a 50 us chain on the
+  // optimiser step's critical path); fixed association, so the result does not depend on the launch
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = threadIdx.x;
+  for (; b + 7 * 256 < nblk; b += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[b + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += v[u];
+  }
+  for (; b < nblk; b += 256) acc[0] += partial[b];
+  float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   s = block_sum<256>(s, sm);
   if (threadIdx.x == 0) {
     const float norm = sqrtf(s);

@@ -192,6 +192,7 @@ class VLPythiaForCausalLM(nn.Module):
         self._side = None
         self._view_cache: Dict[Tuple[int, str], torch.Tensor] = {}
         self.overlap_param_grads = True  # run dW / bias-gradient kernels on side_stream() concurrently with the dX chain
+        self.defer_ln_param_reduce = True   # LayerNorm parameter-gradient reduction on a side stream (needs overlap_param_grads)
         self.reset_parameters(seed)
         self.register_load_state_dict_post_hook(lambda m, ik: setattr(m, "_shadow_dirty", True))
 
@@ -697,6 +698,10 @@ class VLPythiaForCausalLM(nn.Module):
                 self.grad_ready_hook(i)
             on_side(run, k=0)
 
+        # deferred LayerNorm parameter reduction: only with side streams and when no external hidden-state gradient adds into the
+        # same bias gradients from the main stream (generic autograd path of the cosine / CLS losses)
+        defer_ln = (sides is not None and self.defer_ln_param_reduce and taps is None
+                    and not any(d is not None for d in dhidden))
         dx = None  # gradient w.r.t. the residual stream leaving the current layer, fp32 [rows, h]
         if dloss is not None and sv["loss"] is not None:
             xt, lnf, fmean, frstd = sv["final"]
@@ -760,16 +765,26 @@ class VLPythiaForCausalLM(nn.Module):
             wgrad(dqkv, s["ln1"], pre + "attention.query_key_value.weight")
             dln1 = ops.gemm(dqkv, w(pre + "attention.query_key_value.weight"), False, False)
             # both LayerNorms + the residual path, one pass; also emits the compute-dtype copy the next layer's GEMMs read
-            dx, dy = ops.layernorm_bwd(dln1, dln2, s["x"], s["mean"], s["rstd"], self._p(pre + "input_layernorm.weight"),
-                                       self._p(pre + "post_attention_layernorm.weight"), dx,
-                                       g(pre + "input_layernorm.weight"), g(pre + "input_layernorm.bias"),
-                                       g(pre + "post_attention_layernorm.weight"), g(pre + "post_attention_layernorm.bias"),
-                                       want_lp=(cd != torch.float32),
-                                       teacher=inj[0].view(rows, h) if inj is not None else None, attention_mask=am if inj is not None else None,
-                                       S=S, P=P, inj_scale=inj[1] if inj is not None else None, inj_mul=2.0 / h,
-                                       dxsum_a=g(f"gpt_neox.layers.{i - 1}.mlp.dense_4h_to_h.bias") if i > 0 else None,
-                                       dxsum_b=g(f"gpt_neox.layers.{i - 1}.attention.dense.bias") if i > 0 else None)
-            main_moved()
+            ln_kw = dict(want_lp=(cd != torch.float32), teacher=inj[0].view(rows, h) if inj is not None else None,
+                         attention_mask=am if inj is not None else None, S=S, P=P, inj_scale=inj[1] if inj is not None else None, inj_mul=2.0 / h)
+            dxa = g(f"gpt_neox.layers.{i - 1}.mlp.dense_4h_to_h.bias") if i > 0 else None
+            dxb = g(f"gpt_neox.layers.{i - 1}.attention.dense.bias") if i > 0 else None
+            if defer_ln:
+                # row kernel on the dX chain; the slab reduction into the LayerNorm / bias gradients goes to a side stream (it feeds
+                # parameter gradients only, and on the main stream the whole chip waited for it once per layer)
+                dx, dy, ln_ws = ops.layernorm_bwd_rows(dln1, dln2, s["x"], s["mean"], s["rstd"], self._p(pre + "input_layernorm.weight"),
+                                                       self._p(pre + "post_attention_layernorm.weight"), dx, want_dxsum=i > 0, **ln_kw)
+                main_moved()
+                on_side(lambda ws=ln_ws, pre=pre, dxa=dxa, dxb=dxb: ops.layernorm_bwd_params(
+                    ws, rows, h, g(pre + "input_layernorm.weight"), g(pre + "input_layernorm.bias"),
+                    g(pre + "post_attention_layernorm.weight"), g(pre + "post_attention_layernorm.bias"), dxa, dxb), ln_ws)
+            else:
+                dx, dy = ops.layernorm_bwd(dln1, dln2, s["x"], s["mean"], s["rstd"], self._p(pre + "input_layernorm.weight"),
+                                           self._p(pre + "post_attention_layernorm.weight"), dx,
+                                           g(pre + "input_layernorm.weight"), g(pre + "input_layernorm.bias"),
+                                           g(pre + "post_attention_layernorm.weight"), g(pre + "post_attention_layernorm.bias"),
+                                           dxsum_a=dxa, dxsum_b=dxb, **ln_kw)
+                main_moved()
             dy_bias_done = i > 0
             if cd == torch.float32:
                 dy = dx

@@ -144,6 +144,26 @@ def layernorm_bwd(dy1, dy2, x, mean, rstd, w1, w2, dres, dw1, db1, dw2=None, db2
     return dx, dx_lp
 
 
+def layernorm_bwd_rows(dy1, dy2, x, mean, rstd, w1, w2, dres, want_lp: bool = False, teacher=None, attention_mask=None, S: int = 0, P: int = 0,
+                       inj_scale=None, inj_mul: float = 1.0, want_dxsum: bool = False):
+    """Row kernel of the LayerNorm backward alone -> (dx, dx_lp, partials); ``partials`` is a private buffer that
+    ``layernorm_bwd_params`` folds into the parameter gradients later (on another stream, ordered by the caller)."""
+    rows, h = x.shape
+    dx = torch.empty((rows, h), dtype=torch.float32, device=x.device)
+    dx_lp = torch.empty((rows, h), dtype=dy1.dtype, device=x.device) if want_lp else None
+    lib = _lib.load()
+    ws = torch.empty(lib.mafed_layernorm_bwd_workspace_bytes(rows, h), dtype=torch.uint8, device=x.device)
+    check(lib.mafed_layernorm_bwd_rows(_ptr(dy1), _ptr(dy2), _dt(dy1), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w1), _ptr(w2), rows, h, _ptr(dres),
+                                       _ptr(dx), _ptr(dx_lp), _ptr(teacher), _ptr(attention_mask), S, P, S - P, _ptr(inj_scale), float(inj_mul),
+                                       1 if want_dxsum else 0, _ptr(ws), ws.numel(), _stream()), "mafed_layernorm_bwd_rows")
+    return dx, dx_lp, ws
+
+
+def layernorm_bwd_params(ws: torch.Tensor, rows: int, h: int, dw1, db1, dw2=None, db2=None, dxsum_a=None, dxsum_b=None) -> None:
+    check(_lib.load().mafed_layernorm_bwd_params(rows, h, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dxsum_a), _ptr(dxsum_b), _ptr(ws),
+                                                 ws.numel(), _stream()), "mafed_layernorm_bwd_params")
+
+
 def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, D: int, rot: int, cos, sin, attention_mask: torch.Tensor):
     T = attention_mask.shape[1]
     out = torch.empty((B * S, H * D), dtype=qkv.dtype, device=qkv.device)

@@ -38,11 +38,11 @@ with KernelProfile() as kp:
         tr.step(tb, 8 + i)
     torch.cuda.synchronize()
 recs, st = kp.records(), kp.starts_ms
-# step boundaries: the gradnorm launch (one per step)
-gn = [i for i, r in enumerate(recs) if r[0] == "gradnorm"]
+# step boundaries: the embedding backward (one per step, the last kernel of the dX chain; the clip norm is now one launch per range)
+gn = [i for i, r in enumerate(recs) if r[0] == "embed_concat_bwd"]
 print("records", len(recs), "steps", len(gn), "span %.2f ms" % (max(s + r[2] for s, r in zip(st, recs)) - min(st)))
 for k in range(2, N - 1):
-    t0 = st[gn[k]] + recs[gn[k]][2]          # end of clip of step k = start of the window
+    t0 = st[gn[k]] + recs[gn[k]][2]          # end of the backward of step k = start of the window
     t1 = st[gn[k + 1]] + recs[gn[k + 1]][2]
     inwin = [(s - t0, r) for s, r in zip(st, recs) if t0 <= s < t1]
     print(f"-- window {k}: {t1 - t0:.2f} ms, {len(inwin)} kernels")
@@ -65,3 +65,14 @@ for k in range(2, N - 1):
         hist[depth] = hist.get(depth, 0.0) + (t - last)
         last, depth = t, depth + d
     print("   overlap depth (ms): " + ", ".join(f"{d}:{v:.2f}" for d, v in sorted(hist.items())))
+    # the longest stretches with nothing running (start, length, kernel before -> kernel after)
+    iv = sorted((s, s + r[2], r[0]) for s, r in inwin)
+    gaps, end, prev = [], iv[0][1], iv[0][2]
+    for s, e, name in iv[1:]:
+        if s > end:
+            gaps.append((s - end, end, prev, name))
+        if e > end:
+            end, prev = e, name
+    gaps.sort(reverse=True)
+    print("   idle: %d gaps, %.2f ms; longest: " % (len(gaps), sum(g_[0] for g_ in gaps)) +
+          " | ".join(f"{g_[0]*1e3:.0f}us at {g_[1]:.2f} ({g_[2]} -> {g_[3]})" for g_ in gaps[:10]))
