@@ -245,6 +245,9 @@ int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps
 
 /* ---- small utilities --------------------------------------------------------------------------------------------- */
 int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype dst_dtype, int64_t n, void* stream);
+/* dst [B,S,h] fp32 = zeros for the P image positions of every sample, src [B,S-P,h] for its text positions; dst_lp (bf16, optional): the
+ * same rows in the compute dtype.  The start of the residual-stream gradient: only text positions feed the LM head (vl_pythia.py:310). */
+int mafed_pad_text_rows(const float* src, int B, int S, int P, int h, float* dst, void* dst_lp, void* stream);
 /* y = gelu_erf(x) elementwise (used by tests; the product path fuses GELU into mafed_gemm) */
 int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream);
 

@@ -145,7 +145,36 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__
 
 }  // namespace mafed
 
+namespace mafed {
+// dst[b, s, :] = s < P ? 0 : src[b, s - P, :]  (fp32), plus the same rows in bf16 when dst_lp != NULL: the gradient of the residual
+// stream entering the top layer's backward -- only the T text positions reach the LM head -- and the compute-dtype copy its GEMMs
+// read, in one pass (was a 38 MB fill, a strided copy and a cast: three small kernels on the dX chain between forward and backward).
+__global__ __launch_bounds__(256) void pad_text_rows_kernel(const float* __restrict__ src, int S, int P, int h4, int64_t n4, float* __restrict__ dst,
+                                                            bf16_t* __restrict__ dst_lp) {
+  const int T = S - P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / h4;
+    const int c = (int)(i - row * h4);
+    const int64_t b = row / S;
+    const int s_ = (int)(row - b * S);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s_ >= P) v = load4(src + ((b * T + (s_ - P)) * (int64_t)h4 + c) * 4);
+    store4(dst + i * 4, v);
+    if (dst_lp) store4(dst_lp + i * 4, v);
+  }
+}
+}  // namespace mafed
+
 using namespace mafed;
+
+extern "C" int mafed_pad_text_rows(const float* src, int B, int S, int P, int h, float* dst, void* dst_lp, void* stream) {
+  MAFED_CHECK_ARG(src && dst && B > 0 && S > 0 && P >= 0 && P < S && h > 0 && h % 4 == 0, "pad_text_rows: bad arguments");
+  const int64_t n4 = (int64_t)B * S * (h / 4);
+  launch(K_CAST, (double)B * h * ((S - P) * 4.0 + S * (4.0 + (dst_lp ? 2.0 : 0.0))), pad_text_rows_kernel, dim3(grid_for(n4)), dim3(256), 0, as_stream(stream), src, S, P,
+         h / 4, n4, dst, (bf16_t*)dst_lp);
+  MAFED_CHECK_LAUNCH("pad_text_rows");
+  return MAFED_OK;
+}
 
 extern "C" int mafed_cast(const void* src, mafed_dtype sd, void* dst, mafed_dtype dd, int64_t n, void* stream) {
   MAFED_CHECK_ARG(src && dst && n >= 0, "cast: bad arguments");

@@ -715,13 +715,20 @@ class VLPythiaForCausalLM(nn.Module):
                 ops.gemm(dlog, w("embed_out.weight"), False, False, out=dlnf, beta=1.0)
             else:
                 dlnf = ops.gemm(dlog, w("embed_out.weight"), False, False)
-            dxt, _ = ops.layernorm_bwd(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None,
-                                       g("gpt_neox.final_layer_norm.weight"), g("gpt_neox.final_layer_norm.bias"))
-            dx = torch.zeros((rows, h), dtype=torch.float32, device=dev)
-            dx.view(B, S, h)[:, P:, :] = dxt.view(B, T, h)
+            if defer_ln:
+                dxt, _, fws = ops.layernorm_bwd_rows(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None)
+                main_moved()
+                on_side(lambda ws=fws: ops.layernorm_bwd_params(ws, B * T, h, g("gpt_neox.final_layer_norm.weight"),
+                                                                g("gpt_neox.final_layer_norm.bias")), fws)
+            else:
+                dxt, _ = ops.layernorm_bwd(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None,
+                                           g("gpt_neox.final_layer_norm.weight"), g("gpt_neox.final_layer_norm.bias"))
+            dx, dy0 = ops.pad_text_rows(dxt, B, S, P, cd if cd != torch.float32 else None)
             main_moved()
             ready(L)
-        dy = None  # dx in compute dtype (GEMM operand)
+        else:
+            dy0 = None
+        dy = dy0  # dx in compute dtype (GEMM operand)
         dy_bias_done = False  # colsum(dy) already accumulated into this layer's two residual-branch bias gradients
         for i in range(L - 1, -1, -1):
             ext = dhidden[i + 1] if (i + 1) < min(len(dhidden), L) else None  # grad of hidden_states[i+1] = output of layer i

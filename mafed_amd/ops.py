@@ -366,6 +366,15 @@ def gradnorm_clip(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor]
     return out2
 
 
+def pad_text_rows(src: torch.Tensor, B: int, S: int, P: int, lp_dtype=None):
+    """[B*(S-P), h] fp32 -> ([B*S, h] fp32 with zero image rows, the same in ``lp_dtype`` (bf16) or None)"""
+    h = src.shape[-1]
+    dst = torch.empty((B * S, h), dtype=torch.float32, device=src.device)
+    lp = torch.empty((B * S, h), dtype=lp_dtype, device=src.device) if lp_dtype == torch.bfloat16 else None
+    check(_lib.load().mafed_pad_text_rows(_ptr(src), B, S, P, h, _ptr(dst), _ptr(lp), _stream()), "mafed_pad_text_rows")
+    return dst, lp
+
+
 def gradnorm_blocks(n: int) -> int:
     return int(_lib.load().mafed_gradnorm_blocks(int(n)))
 
