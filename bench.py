@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-image-leg", action="store_true", help="skip the image-input measurement (CLIP-ViT-L/14 tower in front of the step)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
+    ap.add_argument("--dense-head", action="store_true", help="LM head, CE and the head's gradient GEMMs on all 32 text positions (A/B)")
     ap.add_argument("--no-defer-ln", action="store_true", help="LayerNorm parameter reduction on the dX stream (A/B)")
     ap.add_argument("--no-incremental-norm", action="store_true", help="clip norm in one pass at the start of the optimiser step (A/B)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
@@ -192,6 +193,8 @@ def main():
     fd.num_vision_tokens = P
     if args.no_defer_ln:
         student.defer_ln_param_reduce = False
+    if args.dense_head:
+        student.sparse_lm_head = False
     if args.no_overlap:
         student.overlap_param_grads = False
         fd.overlap_teacher = False
@@ -370,6 +373,13 @@ def main():
         samples = args.steps * B * world
         value = samples / dt
         flops_step = algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size) * B
+        head_rows = B * T
+        hint = getattr(mem, "max_label_rows", None)
+        if student.sparse_lm_head and hint is not None and getattr(mem, "attach_label_hint", False):
+            rc = next((r for r in range(hint + 1, T + 1) if (B * r) % 128 == 0), None) if cd == torch.bfloat16 else hint + 1
+            if rc is not None and rc * 2 <= T:
+                head_rows = B * rc
+        flops_exec = flops_step - 3.0 * 2.0 * cfg.hidden_size * cfg.vocab_size * (B * T - head_rows)
         roof, kernels = None, None
         if prof_step and "gemm_bf16" in prof_step:
             gm = prof_step["gemm_bf16"]
@@ -423,7 +433,11 @@ def main():
                           "random_init_weights": True},
                "ranks_joined": ranks_joined, "dist_backend": backend,
                "step_tflops_algorithmic": round(flops_step / 1e12, 3),
-               "mfma_frac_whole_step": round(flops_step * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5)}
+               "mfma_frac_whole_step": round(flops_exec * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5)}
+        if head_rows != B * T:
+            # SURVEY 8d counts the LM head on all T text positions; the row-sparse head runs it (forward + both gradient GEMMs) on the
+            # rows that carry a label -- `mfma_frac_whole_step` is priced on the flops actually executed
+            out["lm_head"] = {"rows_per_step": head_rows, "of": B * T, "step_tflops_executed": round(flops_exec / 1e12, 3)}
         if world > 1:
             out["grad_exchange"] = {"mode": args.reduce_mode, "dtype": args.grad_dtype, "bucket_mb": args.bucket_mb,
                                     "MB_per_step": round(tr.reducer.bytes_per_step / 1e6, 1), "buckets": len(tr.reducer.buckets)}

@@ -248,6 +248,13 @@ int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype ds
 /* dst [B,S,h] fp32 = zeros for the P image positions of every sample, src [B,S-P,h] for its text positions; dst_lp (bf16, optional): the
  * same rows in the compute dtype.  The start of the residual-stream gradient: only text positions feed the LM head (vl_pythia.py:310). */
 int mafed_pad_text_rows(const float* src, int B, int S, int P, int h, float* dst, void* dst_lp, void* stream);
+/* Row-sparse LM head (training): the rows of the [B,T] text block whose shifted label is a token (labels[b,t+1] != -100), at most
+ * Rc-1 per sample, as a compact [B,Rc] problem for the same CE kernels: row_of_slot [B*Rc] (text row or -1), slot_of_row [B*T] (slot or
+ * -1), labels_c [B,Rc] (slot n's label at n+1).  overflow[0] = 1 if a sample had more labelled rows than fit.  mafed_gather_rows moves
+ * the rows either way: dst[r,:] = idx[r] >= 0 ? src[idx[r],:] : 0. */
+int mafed_label_rows(const int64_t* labels, int B, int T, int Rc, int* row_of_slot, int* slot_of_row, int64_t* labels_c, int* overflow,
+                     void* stream);
+int mafed_gather_rows(const void* src, mafed_dtype dtype, const int* idx, int64_t n_out, int h, void* dst, void* stream);
 /* y = gelu_erf(x) elementwise (used by tests; the product path fuses GELU into mafed_gemm) */
 int mafed_gelu(const void* x, void* y, mafed_dtype dtype, int64_t n, void* stream);
 

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mafed_optim_advance": (_i, [_p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_pad_text_rows": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "mafed_label_rows": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "mafed_gather_rows": (_i, [_p, _i, _p, _l, _i, _p, _p]),
     "mafed_gelu": (_i, [_p, _p, _i, _l, _p]),
     "mafed_patchify": (_i, [_p, _i, _i, _i, _i, _i, _i, _l, _i, _p, _i, _p]),
     "mafed_vit_assemble": (_i, [_p, _i, _l, _p, _p, _i, _i, _i, _p, _p]),

@@ -163,9 +163,73 @@ __global__ __launch_bounds__(256) void pad_text_rows_kernel(const float* __restr
     if (dst_lp) store4(dst_lp + i * 4, v);
   }
 }
+// Row-sparse LM head (training only): the shifted cross-entropy looks at position t of a sample only when labels[b, t + 1] is a real
+// token -- four answer tokens of 32 text positions in the VQA batches -- so the head's three GEMMs and the two CE passes need only those
+// rows.  One thread per sample lists them: compact slot (b, n) <- text row (b, t), n < Rc - 1 in order of t; labels_c[b, n + 1] is the
+// slot's label, i.e. the compact [B, Rc] problem is again a "position n predicts label n + 1" problem and goes through the same
+// CE kernels (same per-sample counts, same normalisation).  overflow[0] is set when a sample has more labelled rows than Rc - 1.
+__global__ void label_rows_kernel(const int64_t* __restrict__ labels, int B, int T, int Rc, int* __restrict__ row_of_slot,
+                                  int* __restrict__ slot_of_row, int64_t* __restrict__ labels_c, int* __restrict__ overflow) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  labels_c[(int64_t)b * Rc] = -100;
+  for (int t = 0; t < T; ++t) {
+    const bool has = t + 1 < T && labels[(int64_t)b * T + t + 1] != -100;
+    if (has && n < Rc - 1) {
+      row_of_slot[b * Rc + n] = b * T + t;
+      slot_of_row[b * T + t] = b * Rc + n;
+      labels_c[(int64_t)b * Rc + n + 1] = labels[(int64_t)b * T + t + 1];
+      ++n;
+    } else {
+      slot_of_row[b * T + t] = -1;
+      if (has) overflow[0] = 1;
+    }
+  }
+  for (int k = n; k < Rc; ++k) {
+    row_of_slot[b * Rc + k] = -1;
+    if (k + 1 < Rc) labels_c[(int64_t)b * Rc + k + 1] = -100;
+  }
+}
+
+// dst[r, :] = idx[r] >= 0 ? src[idx[r], :] : 0   (16-byte pieces; h % 8 == 0 for bf16, % 4 for fp32)
+template <typename TT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const TT* __restrict__ src, const int* __restrict__ idx, int64_t n_out, int hv,
+                                                          TT* __restrict__ dst) {
+  constexpr int EPV = 16 / sizeof(TT);
+  const int64_t total = n_out * hv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / hv;
+    const int c = (int)(i - r * hv);
+    const int j = idx[r];
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (j >= 0) v = *reinterpret_cast<const uint4*>(src + ((int64_t)j * hv + c) * EPV);
+    *reinterpret_cast<uint4*>(dst + i * EPV) = v;
+  }
+}
 }  // namespace mafed
 
 using namespace mafed;
+
+extern "C" int mafed_label_rows(const int64_t* labels, int B, int T, int Rc, int* row_of_slot, int* slot_of_row, int64_t* labels_c, int* overflow,
+                                void* stream) {
+  MAFED_CHECK_ARG(labels && row_of_slot && slot_of_row && labels_c && overflow && B > 0 && T > 1 && Rc >= 2, "label_rows: bad arguments");
+  label_rows_kernel<<<dim3((B + 63) / 64), dim3(64), 0, as_stream(stream)>>>(labels, B, T, Rc, row_of_slot, slot_of_row, labels_c, overflow);
+  MAFED_CHECK_LAUNCH("label_rows");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_gather_rows(const void* src, mafed_dtype dtype, const int* idx, int64_t n_out, int h, void* dst, void* stream) {
+  MAFED_CHECK_ARG(src && idx && dst && n_out >= 0 && h > 0, "gather_rows: bad arguments");
+  MAFED_CHECK_ARG(h % (dtype == MAFED_F32 ? 4 : 8) == 0, "gather_rows: h=%d must fill 16-byte pieces", h);
+  if (n_out == 0) return MAFED_OK;
+  const int hv = h / (dtype == MAFED_F32 ? 4 : 8);
+  const dim3 grid(grid_for(n_out * hv)), block(256);
+  if (dtype == MAFED_F32) gather_rows_kernel<float><<<grid, block, 0, as_stream(stream)>>>((const float*)src, idx, n_out, hv, (float*)dst);
+  else gather_rows_kernel<bf16_t><<<grid, block, 0, as_stream(stream)>>>((const bf16_t*)src, idx, n_out, hv, (bf16_t*)dst);
+  MAFED_CHECK_LAUNCH("gather_rows");
+  return MAFED_OK;
+}
 
 extern "C" int mafed_pad_text_rows(const float* src, int B, int S, int P, int h, float* dst, void* dst_lp, void* stream) {
   MAFED_CHECK_ARG(src && dst && B > 0 && S > 0 && P >= 0 && P < S && h > 0 && h % 4 == 0, "pad_text_rows: bad arguments");

@@ -758,6 +758,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     // weight-gradient GEMMs (dW += dY^T.X): few output tiles, very long K.  Split K so that the grid fills the chip.
     const int64_t tiles = (M / 128) * (N / 128), nkt = K / 64;
     int ns = g_gemm_split > 1 ? g_gemm_split : (tiles <= 96 ? (nkt >= 512 ? 8 : 4) : (tiles <= 224 ? 2 : 1));  // measured: 64 tiles x4, 192 tiles x2, 256 tiles x1
+    if (g_gemm_split <= 1 && tiles <= 24 && nkt >= 512) ns = 32;  // the row-sparse LM head's dX: 16 tiles over K = 50304
     while (ns > 1 && nkt / ns < 8) ns >>= 1;
     if (cfg == 18) while (ns > 1 && nkt % (2 * ns) != 0) ns >>= 1;
     g_gemm_nsplit = ns;

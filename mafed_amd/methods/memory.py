@@ -34,6 +34,8 @@ class HBMReplayBuffer:
         self._next = None
         self._stream = None
         self.last_ready_event = None
+        self.max_label_rows: Optional[int] = None
+        self.attach_label_hint = True   # batches carry ``max_label_rows`` (row-sparse LM head in training)
 
     def __len__(self) -> int:
         t = self.data["input_ids"]
@@ -54,6 +56,11 @@ class HBMReplayBuffer:
                 v = torch.nn.functional.pad(v, (T - v.shape[1], 0), value=fill)
             self.data[k] = v if cur is None else torch.cat([cur, v], dim=0)
         self._next = None  # a batch gathered ahead of time no longer reflects the buffer
+        # largest number of labelled (shifted) positions of any stored sample: a host-side int that rides along with every batch
+        # (``max_label_rows``) and lets the model run its LM head on the labelled rows only -- known here without touching the GPU
+        # inside the step (add() runs between tasks)
+        lab = self.data["labels"]
+        self.max_label_rows = int((lab[:, 1:] != -100).sum(dim=1).max().item()) if lab is not None and lab.numel() else None
 
     def sample(self) -> Dict[str, torch.Tensor]:
         if self.device.type != "cuda":
@@ -64,7 +71,8 @@ class HBMReplayBuffer:
         batch, ev = self._next
         cur.wait_event(ev)
         for v in batch.values():
-            v.record_stream(cur)  # allocated on the loader stream, consumed here
+            if torch.is_tensor(v):
+                v.record_stream(cur)  # allocated on the loader stream, consumed here
         self.last_ready_event = ev
         self._prefetch(cur)
         return batch
@@ -91,7 +99,10 @@ class HBMReplayBuffer:
             idx = idx.pin_memory().to(self.device, non_blocking=True)
         else:
             idx = idx.to(self.device)
-        return {k: v.index_select(0, idx) for k, v in self.data.items()}
+        out = {k: v.index_select(0, idx) for k, v in self.data.items()}
+        if getattr(self, "max_label_rows", None) is not None and self.attach_label_hint:
+            out["max_label_rows"] = self.max_label_rows
+        return out
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         while True:

@@ -192,6 +192,7 @@ class VLPythiaForCausalLM(nn.Module):
         self._side = None
         self._view_cache: Dict[Tuple[int, str], torch.Tensor] = {}
         self.overlap_param_grads = True  # run dW / bias-gradient kernels on side_stream() concurrently with the dX chain
+        self.sparse_lm_head = True          # batches that carry ``max_label_rows`` get the row-sparse LM head in training
         self.defer_ln_param_reduce = True   # LayerNorm parameter-gradient reduction on a side stream (needs overlap_param_grads)
         self.reset_parameters(seed)
         self.register_load_state_dict_post_hook(lambda m, ik: setattr(m, "_shadow_dirty", True))
@@ -399,9 +400,12 @@ class VLPythiaForCausalLM(nn.Module):
         feats = feats.to(dev).contiguous()
         if torch.is_grad_enabled():
             ctx_box: List[Any] = []
-            outs = _ModelFn.apply(self._anchor, self, feats, input_ids, attention_mask, labels, want_h, ctx_box)
+            # ``max_label_rows`` (an int the replay buffer attaches to its batches): upper bound on the labelled positions of a sample ->
+            # row-sparse LM head (loss and gradients unchanged; ``.logits`` is None then: nothing on the training path reads it)
+            hint = kwargs.get("max_label_rows") if (self.sparse_lm_head and labels is not None) else None
+            outs = _ModelFn.apply(self._anchor, self, feats, input_ids, attention_mask, labels, want_h, ctx_box, hint)
             loss = outs[0] if labels is not None else None
-            logits, hs = outs[1], tuple(outs[3:]) if want_h else None
+            logits, hs = (outs[1] if outs[1].numel() else None), tuple(outs[3:]) if want_h else None
             mctx = (ctx_box[0], outs[2]) if want_h else None
         else:
             mctx = None
@@ -532,7 +536,7 @@ class VLPythiaForCausalLM(nn.Module):
 
     # ---- engine ------------------------------------------------------------------------------------------------------
     def _engine_forward(self, feats, input_ids, attention_mask, labels, want_hidden, train, n_hidden: Optional[int] = None,
-                        keep_qkv: bool = False, qkv_out: Optional[Sequence[torch.Tensor]] = None):
+                        keep_qkv: bool = False, qkv_out: Optional[Sequence[torch.Tensor]] = None, label_rows_hint: Optional[int] = None):
         if not self.flat_params.is_cuda:
             raise RuntimeError("mafed_amd runs on the GPU only (no CPU fallback); move the model with .cuda()")
         pe, main_st = self._param_events, torch.cuda.current_stream()
@@ -610,6 +614,27 @@ class VLPythiaForCausalLM(nn.Module):
             full, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
                                               None, None, cfg.layer_norm_eps, torch.float32, save_stats=False)
             hidden.append(full.view(B, S, h))
+        # Row-sparse head (training, with the caller's bound on labelled positions per sample): only rows whose shifted label is a token
+        # enter the head GEMM, the CE and -- in the backward -- the head's two gradient GEMMs: 4 answer tokens of 32 text positions in
+        # the VQA batches, i.e. 256 of 1024 rows at B = 32 (Rc = slots per sample incl. the unlabelled last one, B * Rc a tile multiple)
+        Rc = None
+        if train and labels is not None and label_rows_hint is not None:
+            need = int(label_rows_hint) + 1
+            Rc = need if cd == torch.float32 else next((r for r in range(need, T + 1) if (B * r) % 128 == 0), None)  # (the MFMA tiles want whole 128-row tiles)
+            if Rc is not None and Rc * 2 > T:
+                Rc = None   # not worth it
+        if Rc is not None:
+            ros, sor, labels_c, ov = ops.label_rows(labels, Rc)
+            self.last_label_overflow = ov   # device flag: 1 if a sample had more labelled positions than the hint promised
+            lnf_c = ops.gather_rows(lnf, ros)
+            logits = ops.gemm(lnf_c, w("embed_out.weight"), False, True).view(B, Rc, cfg.vocab_size)
+            sv["logits"] = logits
+            loss, lse_ce = ops.ce_fwd(logits, labels_c)
+            sv["loss"], sv["ce_lse"] = loss, lse_ce
+            sv["sparse_head"] = (sor, labels_c)
+            sv["final"] = (xt, lnf_c, fmean, frstd)
+            sv["x_last"] = x
+            return sv
         logits = ops.gemm(lnf, w("embed_out.weight"), False, True).view(B, T, cfg.vocab_size)
         sv["logits"] = logits
         if labels is not None:
@@ -707,14 +732,18 @@ class VLPythiaForCausalLM(nn.Module):
             xt, lnf, fmean, frstd = sv["final"]
             logits = sv["logits"]
             gl = dloss.reshape(1).to(torch.float32).contiguous()
-            dlog = ops.ce_bwd(logits, sv["labels"], sv["ce_lse"], gl).view(B * T, cfg.vocab_size)
+            sp = sv.get("sparse_head")   # (slot of every text row, compact labels): the head ran on the labelled rows only
+            n_head = logits.shape[0] * logits.shape[1]
+            dlog = ops.ce_bwd(logits, sp[1] if sp is not None else sv["labels"], sv["ce_lse"], gl).view(n_head, cfg.vocab_size)
             wgrad(dlog, lnf, "embed_out.weight")
             if cd == torch.bfloat16:
-                # [B*T, V] . [V, h]: 64 output tiles with K = 50304 -- accumulate-only fp32 output so that the GEMM splits K
-                dlnf = torch.zeros((B * T, h), dtype=torch.float32, device=dev)
+                # [rows, V] . [V, h]: few output tiles with K = 50304 -- accumulate-only fp32 output so that the GEMM splits K
+                dlnf = torch.zeros((n_head, h), dtype=torch.float32, device=dev)
                 ops.gemm(dlog, w("embed_out.weight"), False, False, out=dlnf, beta=1.0)
             else:
                 dlnf = ops.gemm(dlog, w("embed_out.weight"), False, False)
+            if sp is not None:
+                dlnf = ops.gather_rows(dlnf if dlnf.dtype == torch.float32 else dlnf.float(), sp[0])   # back to the [B*T, h] text rows (zeros elsewhere)
             if defer_ln:
                 dxt, _, fws = ops.layernorm_bwd_rows(dlnf, None, xt, fmean, frstd, self._p("gpt_neox.final_layer_norm.weight"), None, None)
                 main_moved()
@@ -883,15 +912,16 @@ class _ModelFn(torch.autograd.Function):
     """The whole model as one autograd node: outputs (loss, logits, *hidden_states)."""
 
     @staticmethod
-    def forward(ctx, anchor, model: VLPythiaForCausalLM, feats, input_ids, attention_mask, labels, want_hidden, ctx_box):
-        sv = model._engine_forward(feats, input_ids, attention_mask, labels, want_hidden, train=True)
+    def forward(ctx, anchor, model: VLPythiaForCausalLM, feats, input_ids, attention_mask, labels, want_hidden, ctx_box, label_rows_hint=None):
+        sv = model._engine_forward(feats, input_ids, attention_mask, labels, want_hidden, train=True, label_rows_hint=label_rows_hint)
         ctx.model, ctx.sv = model, sv
         ctx_box.append(sv)
         ctx.set_materialize_grads(False)  # outputs nobody differentiated arrive as None, not as zero tensors
         loss = sv["loss"].reshape(()).clone() if sv["loss"] is not None else torch.zeros((), device=anchor.device)
         # outs[2] is a 0-dim "hook": the fused distillation node takes it as an input so that this node's backward runs
         # (after the distillation node has left its per-layer coefficients in sv["inject"]) even without a CE gradient
-        outs = [loss, sv["logits"].detach(), torch.zeros((), device=anchor.device)]
+        pub = sv["logits"] if sv.get("sparse_head") is None else torch.empty(0, device=anchor.device)   # compact logits are internal
+        outs = [loss, pub.detach(), torch.zeros((), device=anchor.device)]
         ctx.mark_non_differentiable(outs[1])
         if want_hidden:
             outs += [x.detach() for x in sv["hidden"]]  # aliases: no reference cycle through ctx
@@ -907,7 +937,7 @@ class _ModelFn(torch.autograd.Function):
             dloss = None
         ctx.model._engine_backward(sv, dloss, list(dhidden))
         sv.pop("inject", None)
-        return (None,) * 8
+        return (None,) * 9
 
 
 model_architecture = {"vlpythia": VLPythiaForCausalLM}

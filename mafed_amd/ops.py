@@ -375,6 +375,26 @@ def pad_text_rows(src: torch.Tensor, B: int, S: int, P: int, lp_dtype=None):
     return dst, lp
 
 
+def label_rows(labels: torch.Tensor, Rc: int):
+    """labels [B,T] int64 -> (row_of_slot [B*Rc] int32, slot_of_row [B*T] int32, labels_c [B,Rc] int64, overflow [1] int32)"""
+    B, T = labels.shape
+    dev = labels.device
+    ros = torch.empty(B * Rc, dtype=torch.int32, device=dev)
+    sor = torch.empty(B * T, dtype=torch.int32, device=dev)
+    lc = torch.empty((B, Rc), dtype=torch.int64, device=dev)
+    ov = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(_lib.load().mafed_label_rows(_ptr(labels), B, T, Rc, _ptr(ros), _ptr(sor), _ptr(lc), _ptr(ov), _stream()), "mafed_label_rows")
+    return ros, sor, lc, ov
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """dst[r] = src[idx[r]] (zeros where idx[r] < 0); src [n,h] contiguous fp32 / bf16, idx int32"""
+    h = src.shape[-1]
+    dst = torch.empty((idx.numel(), h), dtype=src.dtype, device=src.device)
+    check(_lib.load().mafed_gather_rows(_ptr(src), _dt(src), _ptr(idx), idx.numel(), h, _ptr(dst), _stream()), "mafed_gather_rows")
+    return dst
+
+
 def gradnorm_blocks(n: int) -> int:
     return int(_lib.load().mafed_gradnorm_blocks(int(n)))
 
