@@ -827,6 +827,10 @@ class VLPythiaForCausalLM(nn.Module):
             if taps is not None and i in taps:
                 taps[i] = dx  # = dL/d hidden_states[i] (fresh buffer, never written again on this path)
             ready(i)
+        # every layer's LayerNorm / distillation kernel -- the last readers of the teacher's hidden states -- is queued: a consumer
+        # that only has to stay behind THOSE (the next step's teacher forward re-uses that memory) can wait for this event instead of
+        # for the whole backward, whose side streams still carry ~0.3 ms of parameter-gradient tail
+        self.dx_chain_event = main.record_event()
         ext0 = dhidden[0] if len(dhidden) > 0 else None
         if ext0 is not None:
             ext0 = ext0.reshape(rows, h)

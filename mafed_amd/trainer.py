@@ -20,6 +20,11 @@ from mafed_amd.dist import GradReducer
 from mafed_amd.optim import FlatAdamW, compute_warmup, get_linear_schedule_with_warmup
 
 
+import os as _os
+
+_EARLY_TEACHER = _os.environ.get("MAFED_EARLY_TEACHER", "1") != "0"   # A/B switch
+
+
 class Trainer:
     def __init__(self, model, cl_method, config: Optional[Any] = None, task_id: int = 0, n_batches_per_epoch: int = 1000,
                  process_group=None, ddp: bool = False, bucket_mb: float = 64.0, pipeline_optimizer: bool = False,
@@ -99,7 +104,11 @@ class Trainer:
         (loss / self.accumulate if self.accumulate != 1 else loss).backward()
         if torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
             # lets the next step's frozen-teacher forward start here, under this step's clip + AdamW
-            self.cl_method.backward_done_event = torch.cuda.current_stream().record_event()
+            # (the model's own event marks the end of the dX chain: the teacher forward then starts under the parameter-gradient tail)
+            ev = getattr(self.model, "dx_chain_event", None) if _EARLY_TEACHER else None
+            self.cl_method.backward_done_event = ev if ev is not None else torch.cuda.current_stream().record_event()
+            if ev is not None:
+                self.model.dx_chain_event = None
         rec: Dict[str, Any] = {"loss": loss.detach(), "branch": branch, "stepped": False}
         if window_end:
             self.cl_method.update_after_backward(model=self.model)  # on_before_optimizer_step
