@@ -213,7 +213,9 @@ class FeatureDistillation(CLStrategy):
         finally:
             if hooked:
                 model.hidden_ready_hook = None
-        loss = self.replay_coeff * output.loss if do_replay else None
+        # (x * 1.0 is x: with the default coefficient the product and its backward are two scalar kernels on the stream between the
+        # forward and the backward for nothing)
+        loss = (output.loss if self.replay_coeff == 1.0 else self.replay_coeff * output.loss) if do_replay else None
         if self.distillation_coeff == 0:
             return loss, n_ex
         dloss = self.distill(output=output, batch=batch)
