@@ -25,6 +25,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
+import os as _os
+
 import torch
 from torch import nn
 
@@ -307,7 +309,7 @@ class VLPythiaForCausalLM(nn.Module):
         return self
 
     # ---- streams ---------------------------------------------------------------------------------------------------
-    N_SIDE = 3
+    N_SIDE = int(_os.environ.get("MAFED_N_SIDE", "3"))   # parameter-gradient streams; same-box A/B on the round-2 build: 1 -> 33.4, 2 -> 34.0, 3 -> 33.4, 4 -> 33.8 ms
 
     def side_streams(self):
         """Extra HIP streams of this replica: parameter-gradient GEMMs (dW = dY^T.X, bias column sums) run here, off the
