@@ -7,6 +7,12 @@ hand-written HIP kernels behind the C-ABI of ``include/mafed_hip.h`` (``libmafed
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# HIP runtime option (read when the runtime initialises; a value the user has set wins): kernel arguments in device memory, which
+# shortens the launch-to-launch latency the hand-scheduled step is sensitive to
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 from mafed_amd.methods import CLMethod, CLStrategy, ER, EWC, FeatureDistillation, Naive  # noqa: F401
 from mafed_amd.model import VLPythiaConfig, VLPythiaForCausalLM, model_architecture  # noqa: F401
 from mafed_amd.optim import FlatAdamW, get_linear_schedule_with_warmup  # noqa: F401
