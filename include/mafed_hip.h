@@ -71,6 +71,22 @@ int mafed_gemm_colsum(mafed_dtype in_dtype, int transA, int transB, int64_t M, i
                       const float* bias, int epilogue, void* aux,
                       const float* res1, const float* res2, float beta, float* colsum, void* stream);
 
+/* Grouped form: n independent products with the same operand layouts (transA / transB), input and output types, each with its own
+ * shape, leading dimensions and epilogue (fields as the arguments of mafed_gemm_colsum).  Where every problem tiles the persistent
+ * MFMA kernel they run as ONE launch whose tile space is the concatenation of theirs -- the parameter gradients dW += dY^T.X of several
+ * layers fill the 256 CUs in whole rounds that way, without split-K -- otherwise as n launches.  Same results as n mafed_gemm_colsum
+ * calls.  Replaces: the per-parameter weight-gradient products of autograd's Linear backward (tf:38-49,192-236), batched across layers. */
+typedef struct mafed_gemm_problem {
+  int64_t M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias; int epilogue; void* aux;
+  const float* res1; const float* res2; float beta; float* colsum;
+} mafed_gemm_problem;
+int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, mafed_dtype c_dtype,
+                       const mafed_gemm_problem* problems, int n, void* stream);
+
 /* out[n] += sum_m X[m,n]   (bias gradients; X dtype bf16/f32, out fp32 accumulated with one atomic per column per
  * 256-row block; N, ldx multiples of 4).  workspace is unused (kept for ABI stability; workspace_bytes may be 0). */
 size_t mafed_colsum_workspace_bytes(int64_t M, int64_t N);
@@ -290,6 +306,10 @@ const char* mafed_prof_tag_name(int tag);
  * 10 + c = force LDS-DMA tile configuration c; 100 = automatic split-K for accumulate-only outputs, 101 = no split-K,
  * 100 + n = force n K-splits where legal */
 int mafed_gemm_set_variant(int variant);
+/* 700 = never take the persistent ping-pong kernel, 701 = automatic (default), 710 + c = force its tile configuration c
+ * (0: 256x256, 1: 192x256, 2: 144x256) wherever the shape tiles it.  mafed_gemm_pp_launches(): launches that took that kernel so far
+ * (tests assert that a forced configuration really ran). */
+int mafed_gemm_pp_launches(void);
 
 /* test / tuning hook: 0 = automatic (one-block-per-head "resident" kernels when K/V fit in LDS), 1 = tiled kernels only */
 int mafed_attn_set_variant(int variant);

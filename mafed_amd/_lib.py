@@ -23,7 +23,9 @@ SIGNATURES = {
     "mafed_last_error_string": (C.c_char_p, []),
     "mafed_gemm": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p]),
     "mafed_gemm_colsum": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p, _p]),
+    "mafed_gemm_grouped": (_i, [_i, _i, _i, _i, _p, _i, _p]),
     "mafed_gemm_set_variant": (_i, [_i]),
+    "mafed_gemm_pp_launches": (_i, []),
     "mafed_attn_decode": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "mafed_ewc_workspace_bytes": (_z, [_l]),
     "mafed_ewc_penalty_fwd": (_i, [_p, _p, _p, _l, _f, _f, _p, _p, _z, _p]),
@@ -71,6 +73,14 @@ SIGNATURES = {
     "mafed_prof_collect": (_i, [_p, _p, _p, _p, _i]),
     "mafed_prof_tag_name": (C.c_char_p, [_i]),
 }
+
+
+
+class GemmProblem(C.Structure):
+    """``mafed_gemm_problem`` of include/mafed_hip.h (one entry of a grouped launch)."""
+    _fields_ = [("M", _l), ("N", _l), ("K", _l), ("A", _p), ("lda", _l), ("B", _p), ("ldb", _l), ("C", _p), ("ldc", _l),
+                ("bias", _p), ("epilogue", _i), ("aux", _p), ("res1", _p), ("res2", _p), ("beta", _f), ("colsum", _p)]
+
 
 _lib: Optional[C.CDLL] = None
 

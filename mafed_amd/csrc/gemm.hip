@@ -18,6 +18,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "gemm_tiles.h"
+#include "gemm_pp.h"
 
 #ifndef MAFED_GEMM_SPREAD_DMA
 #define MAFED_GEMM_SPREAD_DMA 0  // measured twice (also with a hand-ordered, fence-pinned row schedule): a DMA piece between MFMA rows is 1.1-1.6x SLOWER than the burst (fc1 114 -> 177 us)
@@ -638,8 +639,13 @@ static int g_gemm_variant = 0;
 static int g_gemm_big = 0;    // 288x256 configuration in automatic mode (200 = off, 201 = on): faster alone, slower beside the side streams
 static int g_gemm_kgroups = 0;  // two K groups per block for the one-tile-per-CU weight gradients (400 = off, 401 = on): 9 % faster alone, 2.5 % slower step (no dX block fits beside a 128 KiB block)
 static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n splits where legal
+static int g_gemm_pp = 1;        // persistent ping-pong kernel (gemm_pp.hip): 700 = off, 701 = automatic (default), 710 + c = force configuration c
+static int g_gemm_pp_force = -1;
+static int g_gemm_pp_launches = 0;   // test hook: how many launches took the ping-pong kernel
+extern "C" int mafed_gemm_pp_launches(void) { return g_gemm_pp_launches; }
 namespace mafed { extern int g_skinny_ns, g_skinny_wide; }
 extern "C" int mafed_gemm_set_variant(int v) {
+  if (v >= 700 && v < 800) { g_gemm_pp = v == 700 ? 0 : 1; g_gemm_pp_force = v >= 710 ? v - 710 : -1; return MAFED_OK; }
   if (v >= 600) { g_skinny_wide = v == 699 ? -1 : v - 600; return MAFED_OK; }
   if (v >= 500) { g_skinny_ns = v - 500; return MAFED_OK; }
   if (v >= 400) { g_gemm_kgroups = v - 400; return MAFED_OK; }
@@ -664,6 +670,67 @@ extern "C" int mafed_gemm_colsum(mafed_dtype in_dtype, int transA, int transB, i
                                  const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
                                  void* aux, const float* res1, const float* res2, float beta, float* colsum, void* stream) {
   return gemm_impl(in_dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, epilogue, aux, res1, res2, beta, colsum, stream);
+}
+
+// Problem record of the ping-pong kernel; false when the epilogue / alignment is outside what that kernel stores directly
+// (16-byte row segments: every pointer 16-byte aligned, ldc a multiple of 8; fused column sums only in its prefetching epilogues).
+static bool pp_fill_problem(PPProblem& pr, bool a_ks, bool b_ks, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                            int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const GemmEpi& epi, float* colsum) {
+  (void)a_ks; (void)b_ks; (void)M; (void)N; (void)K;
+  const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)epi.aux | (uintptr_t)epi.res1 | (uintptr_t)epi.res2 |
+                       (uintptr_t)epi.bias | (uintptr_t)colsum;
+  if ((al & 15) || ldc % 8 || lda % 8 || ldb % 8) return false;
+  const bool r1 = epi.res1 != nullptr, r2 = epi.res2 != nullptr, bt = epi.beta != 0.f, pair = c_dtype == MAFED_BF16;
+  const bool fast = (epi.mode == MAFED_EPI_NONE && !r1 && !r2 && !bt) || (epi.mode == MAFED_EPI_GELU && !r1 && !r2 && !bt) ||
+                    (pair && epi.mode == MAFED_EPI_GELU_BWD && !r1 && !r2 && !bt) ||
+                    (epi.mode == MAFED_EPI_NONE && r1 && epi.res1_bf16 && r2 && !bt) || (!pair && epi.mode == MAFED_EPI_NONE && !r1 && !r2 && bt);
+  if (colsum && !fast) return false;
+  pr.A = (const bf16_t*)A; pr.B = (const bf16_t*)B; pr.C = C;
+  pr.bias = epi.bias; pr.aux = epi.aux; pr.res1 = epi.res1; pr.res2 = epi.res2; pr.colsum = colsum;
+  pr.lda = lda; pr.ldb = ldb; pr.ldc = ldc;
+  pr.beta = epi.beta; pr.mode = epi.mode; pr.res1_bf16 = epi.res1_bf16;
+  pr.tiles_m = pr.tiles_n = pr.nkt = pr.tile_begin = pr.pad_ = 0;
+  return true;
+}
+
+/* Several independent products C_i = op(A_i).op(B_i) (same operand layouts, input and output types) as ONE launch of the persistent
+ * kernel where their shapes tile it; otherwise one launch each. */
+extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, mafed_dtype c_dtype, const mafed_gemm_problem* problems, int n,
+                                  void* stream) {
+  MAFED_CHECK_ARG(problems && n >= 1, "gemm_grouped: no problems");
+  bool one = in_dtype == MAFED_BF16 && n <= PP_MAXP && ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0);
+  const bool a_ks = transA != 0, b_ks = transB == 0;
+  PPProblem pr[PP_MAXP];
+  int64_t Ms[PP_MAXP], Ns[PP_MAXP], Ks[PP_MAXP];
+  int cfg = PP_NONE;
+  for (int i = 0; one && i < n; ++i) {
+    const mafed_gemm_problem& q = problems[i];
+    const int res1_bf16 = (q.epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
+    GemmEpi epi{q.bias, q.epilogue & ~MAFED_EPI_RES1_BF16, q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
+    one = q.A && q.B && q.C && q.M > 0 && (c_dtype == MAFED_F32 || q.beta == 0.f) && !(q.colsum && q.beta != 0.f) &&
+          pp_fill_problem(pr[i], a_ks, b_ks, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, epi, q.colsum);
+    Ms[i] = q.M; Ns[i] = q.N; Ks[i] = q.K;
+    if (one) {
+      // one configuration for the whole group: the one the first problem picks must tile the others too
+      const int c = gemm_pp_pick(a_ks, b_ks, c_dtype, q.M, q.N, q.K, i == 0 ? g_gemm_pp_force : cfg);
+      if (i == 0) cfg = c;
+      one = c != PP_NONE && c == cfg;
+    }
+  }
+  if (one) {
+    const int rc = gemm_pp_launch(cfg, a_ks, b_ks, c_dtype, pr, n, Ms, Ns, Ks, as_stream(stream));
+    if (rc != MAFED_OK) return rc;
+    MAFED_CHECK_LAUNCH("gemm_grouped(ping-pong)");
+    ++g_gemm_pp_launches;
+    return MAFED_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const mafed_gemm_problem& q = problems[i];
+    const int rc = gemm_impl(in_dtype, transA, transB, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, q.bias, q.epilogue, q.aux, q.res1,
+                             q.res2, q.beta, q.colsum, stream);
+    if (rc != MAFED_OK) return rc;
+  }
+  return MAFED_OK;
 }
 
 static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
@@ -710,6 +777,20 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     if (rc != MAFED_OK) return rc;
     MAFED_CHECK_LAUNCH("gemm(bf16, skinny)");
     return MAFED_OK;
+  }
+  // persistent ping-pong kernel (gemm_pp.hip): tile-aligned shapes whose tile count fills the 256 CUs in whole rounds
+  if ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0) {
+    PPProblem pr;
+    if (pp_fill_problem(pr, a_ks, b_ks, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, epi, colsum)) {
+      const int pcfg = gemm_pp_pick(a_ks, b_ks, c_dtype, M, N, K, g_gemm_pp_force);
+      if (pcfg != PP_NONE) {
+        rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st);
+        if (rc != MAFED_OK) return rc;
+        MAFED_CHECK_LAUNCH("gemm(bf16, ping-pong)");
+        ++g_gemm_pp_launches;
+        return MAFED_OK;
+      }
+    }
   }
   // variant: 0 automatic, 1 register-staged kernel, 10 + c forces LDS-DMA tile configuration c
   int cfg = -1;

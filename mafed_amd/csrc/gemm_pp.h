@@ -1,0 +1,45 @@
+// Persistent "ping-pong" bf16 MFMA GEMM (gemm_pp.hip): problem table shared by the kernel, the launcher and the dispatcher.
+#pragma once
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace mafed {
+
+constexpr int PP_MAXP = 16;  // problems per grouped launch (kernarg: 16 + 16 x 120 bytes)
+
+// One C = op(A).op(B) problem of a (possibly grouped) persistent launch.  All problems of a launch share the operand
+// layouts (A_KS / B_KS), the output type and the tile configuration; shapes, leading dimensions and epilogues are their own.
+struct PPProblem {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;
+  void* aux;
+  const void* res1;
+  const float* res2;
+  float* colsum;
+  int64_t lda, ldb, ldc;
+  float beta;
+  int mode;       // MAFED_EPI_*
+  int res1_bf16;
+  int tiles_m, tiles_n;
+  int nkt;        // K / 64 (even)
+  int tile_begin; // first tile id of this problem in the launch's tile space
+  int pad_;
+};
+
+struct PPArgs {
+  int nprobs, ntiles, group_m, pad_;
+  PPProblem p[PP_MAXP];
+};
+
+// tile configurations of the ping-pong kernel
+enum PPConfig { PP_NONE = -1, PP_256x256 = 0, PP_192x256 = 1, PP_144x256 = 2 };
+
+// picks a configuration for one problem (or PP_NONE when no configuration tiles the shape exactly / the mode is not instantiated)
+int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N, int64_t K, int force_cfg);
+// launches `n` problems (same layouts / output type / configuration) as ONE persistent grid
+int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,
+                   const int64_t* Ks, hipStream_t st);
+
+}  // namespace mafed

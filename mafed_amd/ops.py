@@ -108,6 +108,40 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
     return out
 
 
+def gemm_grouped(problems, transA: bool, transB: bool) -> None:
+    """Several independent ``C_i = op(A_i) @ op(B_i)`` as one persistent launch (mafed_gemm_grouped).  ``problems``: dicts with the
+    keyword arguments of :func:`gemm` (``A``, ``B``, ``out`` required; ``bias``, ``epilogue``, ``aux``, ``res1``, ``res2``, ``beta``,
+    ``colsum`` optional).  All share the operand layouts, the input dtype and the output dtype."""
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (_lib.GemmProblem * n)()
+    in_dt = out_dt = None
+    for i, q in enumerate(problems):
+        A, B, out = q["A"], q["B"], q["out"]
+        assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+        M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+        N = B.shape[0] if transB else B.shape[1]
+        assert K == (B.shape[1] if transB else B.shape[0]) and out.shape == (M, N)
+        in_dt = _dt(A) if in_dt is None else in_dt
+        out_dt = _dt(out) if out_dt is None else out_dt
+        assert _dt(A) == in_dt and _dt(out) == out_dt, "a grouped launch shares its input and output types"
+        epi = q.get("epilogue", EPI_NONE)
+        res1 = q.get("res1")
+        if res1 is not None and res1.dtype == torch.bfloat16:
+            epi |= EPI_RES1_BF16
+        cs = q.get("colsum")
+        assert cs is None or (cs.dtype == torch.float32 and cs.numel() == N and cs.is_contiguous())
+        g = arr[i]
+        g.M, g.N, g.K = M, N, K
+        g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0)
+        g.bias, g.epilogue, g.aux = _ptr(q.get("bias")), epi, _ptr(q.get("aux"))
+        g.res1, g.res2, g.beta, g.colsum = _ptr(res1), _ptr(q.get("res2")), float(q.get("beta", 0.0)), _ptr(cs)
+    rc = _fn.gemm_grouped(in_dt, int(transA), int(transB), out_dt, arr, n, _stream())
+    if rc:
+        check(rc, "mafed_gemm_grouped")
+
+
 def colsum_(X: torch.Tensor, out: torch.Tensor) -> None:
     """out[n] += sum_m X[m, n]"""
     assert X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32

@@ -1,0 +1,207 @@
+"""GPU parity tests of the persistent ping-pong MFMA GEMM (mafed_amd/csrc/gemm_pp.hip) through the C-ABI: exact-integer products in
+every instantiated (tile configuration x operand layout x output type), several tiles per block, grouped launches, and the fused
+epilogues against fp64 restatements.  Every case asserts that the ping-pong kernel really ran (mafed_gemm_pp_launches)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def _ops():
+    from mafed_amd import ops
+    return ops
+
+
+def _lib():
+    from mafed_amd import _lib
+    return _lib.load()
+
+
+def _int_mat(shape, g, lo=-1, hi=2):
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+def _ref(A, B, tA, tB):
+    a = A.double().t() if tA else A.double()
+    b = B.double().t() if tB else B.double()
+    return a @ b
+
+
+class forced:
+    """mafed_gemm_set_variant(710 + cfg) around a block; checks that the ping-pong kernel launched `expect` times."""
+
+    def __init__(self, cfg, expect=1):
+        self.cfg, self.expect = cfg, expect
+
+    def __enter__(self):
+        self.lib = _lib()
+        self.lib.mafed_gemm_set_variant(710 + self.cfg if self.cfg is not None else 701)
+        self.n0 = self.lib.mafed_gemm_pp_launches()
+
+    def __exit__(self, *a):
+        self.lib.mafed_gemm_set_variant(701)
+        if a[0] is None:
+            assert self.lib.mafed_gemm_pp_launches() - self.n0 == self.expect, "the ping-pong kernel did not take this launch"
+
+
+# (cfg, tA, tB, out dtype): the instantiated combinations (gemm_pp_launch)
+COMBOS = [(1, False, True, BF), (1, False, True, F32), (2, False, True, BF), (2, False, True, F32),
+          (1, False, False, BF), (2, False, False, BF), (0, True, False, F32)]
+TM = {0: 256, 1: 192, 2: 144}
+
+
+@pytest.mark.parametrize("cfg,tA,tB,od", COMBOS)
+@pytest.mark.parametrize("tiles_m,tiles_n,K", [(1, 1, 256), (3, 2, 384), (2, 1, 1024), (5, 3, 256)])
+def test_pp_exact_integers(cfg, tA, tB, od, tiles_m, tiles_n, K):
+    """Small-integer operands are exact in bf16, in the fp32 accumulator and (|sum| <= 256 at K = 256; checked in fp32 otherwise) in
+    the output: a wrong DMA permutation, swizzle, fragment or column map is a hard mismatch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11 + cfg)
+    M, N = TM[cfg] * tiles_m, 256 * tiles_n
+    A = _int_mat((K, M) if tA else (M, K), g)
+    B = _int_mat((N, K) if tB else (K, N), g)
+    if od == BF and K > 256:
+        A = A * (torch.rand(A.shape, generator=g) < 0.3)   # keep |sum| small enough to be exact in bf16
+    with forced(cfg):
+        C = ops.gemm(A.to(DEV, BF), B.to(DEV, BF), tA, tB, out_dtype=od)
+    ref = _ref(A, B, tA, tB)
+    if od == BF:
+        ref = ref.to(BF).double()
+    err = float((C.double().cpu() - ref).abs().max())
+    assert err == 0.0, f"cfg {cfg} tA={tA} tB={tB} {od} {M}x{N}x{K}: max err {err}"
+
+
+@pytest.mark.parametrize("cfg,tA,tB,od", COMBOS)
+def test_pp_many_tiles_per_block(cfg, tA, tB, od):
+    """More tiles than CUs (several tiles per persistent block, a ragged last round) and a tile count that is not a multiple of 8."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    for tiles_m, tiles_n in ((37, 8), (7, 1)):
+        M, N, K = TM[cfg] * tiles_m, 256 * tiles_n, 256
+        A = _int_mat((K, M) if tA else (M, K), g)
+        B = _int_mat((N, K) if tB else (K, N), g)
+        with forced(cfg):
+            C = ops.gemm(A.to(DEV, BF), B.to(DEV, BF), tA, tB, out_dtype=od)
+        ref = _ref(A, B, tA, tB)
+        assert float((C.double().cpu() - ref).abs().max()) == 0.0, (cfg, tiles_m, tiles_n)
+
+
+@pytest.mark.parametrize("cfg,tA,tB,od", COMBOS)
+def test_pp_grouped_launch(cfg, tA, tB, od):
+    """Problems of different shapes and leading dimensions in one launch == the same problems one by one."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(TM[cfg] * 2, 512, 256), (TM[cfg] * 1, 256, 512), (TM[cfg] * 3, 768, 384), (TM[cfg] * 1, 1024, 256)]
+    probs, refs = [], []
+    for (M, N, K) in shapes:
+        A = _int_mat((K, M) if tA else (M, K), g).to(DEV, BF)
+        B = _int_mat((N, K) if tB else (K, N), g).to(DEV, BF)
+        c0 = _int_mat((M, N), g).to(DEV, od) if od == F32 else None
+        out = c0.clone() if c0 is not None else torch.empty((M, N), dtype=od, device=DEV)
+        probs.append(dict(A=A, B=B, out=out, beta=1.0 if od == F32 else 0.0))
+        r = _ref(A.float().cpu(), B.float().cpu(), tA, tB)
+        refs.append(r + c0.double().cpu() if c0 is not None else r)
+    with forced(cfg):
+        ops.gemm_grouped(probs, tA, tB)
+    for q, r in zip(probs, refs):
+        if od == BF:
+            r = r.to(BF).double()
+        assert float((q["out"].double().cpu() - r).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_pp_epilogues_forward(cfg):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = TM[cfg] * 2, 512, 256
+    A, W = torch.randn(M, K, generator=g) * 0.5, torch.randn(N, K, generator=g) * 0.5
+    bias = torch.randn(N, generator=g)
+    r1, r2 = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Wd = A.to(DEV, BF), W.to(DEV, BF)
+    pre = Ad.float().cpu().double() @ Wd.float().cpu().double().t() + bias.double()
+    # bias only
+    with forced(cfg):
+        y = ops.gemm(Ad, Wd, False, True, bias=bias.to(DEV))
+    assert float((y.double().cpu() - pre).abs().max()) <= 1e-2 * float(pre.abs().max())
+    # bias + gelu, pre-activation saved / not saved
+    aux = torch.empty(M, N, dtype=BF, device=DEV)
+    with forced(cfg, 2):
+        y = ops.gemm(Ad, Wd, False, True, bias=bias.to(DEV), epilogue=ops.EPI_GELU, aux=aux)
+        y2 = ops.gemm(Ad, Wd, False, True, bias=bias.to(DEV), epilogue=ops.EPI_GELU)
+    assert float((aux.double().cpu() - pre).abs().max()) <= 1e-2 * float(pre.abs().max())
+    assert float((y.double().cpu() - F.gelu(pre)).abs().max()) <= 1e-2 * float(pre.abs().max())
+    assert torch.equal(y, y2)
+    # bf16 + fp32 residuals into an fp32 C (the parallel-residual add of the MLP down-projection)
+    r1d = r1.to(DEV, BF)
+    with forced(cfg):
+        c = ops.gemm(Ad, Wd, False, True, out_dtype=F32, bias=bias.to(DEV), res1=r1d, res2=r2.to(DEV))
+    want = pre + r1d.double().cpu() + r2.double()
+    assert float((c.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # the same into a bf16 C
+    with forced(cfg):
+        cb = ops.gemm(Ad, Wd, False, True, out_dtype=BF, bias=bias.to(DEV), res1=r1d, res2=r2.to(DEV))
+    assert float((cb.double().cpu() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    # generic epilogue path (fp32 res1 only): in-place operand loads
+    with forced(cfg):
+        cg = ops.gemm(Ad, Wd, False, True, out_dtype=F32, res1=r2.to(DEV))
+    want = pre - bias.double() + r2.double()
+    assert float((cg.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_pp_gelu_backward_with_column_sums(cfg):
+    """dX = dY.W with the GELU' epilogue and the fused bias gradient (column sums of the stored C)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    M, N, K = TM[cfg] * 3, 512, 256
+    dY, W = torch.randn(M, K, generator=g) * 0.5, torch.randn(K, N, generator=g) * 0.5
+    u = torch.randn(M, N, generator=g)
+    dYd, Wd, ud = dY.to(DEV, BF), W.to(DEV, BF), u.to(DEV, BF)
+    cs = torch.zeros(N, device=DEV)
+    with forced(cfg):
+        du = ops.gemm(dYd, Wd, False, False, epilogue=ops.EPI_GELU_BWD, aux=ud, colsum=cs)
+    uu = ud.float().cpu().double().requires_grad_(True)
+    F.gelu(uu).sum().backward()
+    want = (dYd.float().cpu().double() @ Wd.float().cpu().double()) * uu.grad
+    assert float((du.double().cpu() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    assert float((cs.double().cpu() - du.double().cpu().sum(0)).abs().max()) <= 1e-3 * float(du.double().abs().sum(0).max())
+    # plain dX with column sums
+    cs2 = torch.zeros(N, device=DEV)
+    with forced(cfg):
+        dx = ops.gemm(dYd, Wd, False, False, colsum=cs2)
+    assert float((cs2.double().cpu() - dx.double().cpu().sum(0)).abs().max()) <= 1e-3 * float(dx.double().abs().sum(0).max())
+
+
+def test_pp_weight_gradient_accumulates():
+    """dW += dY^T.X (both operands [k][row]) through the 256x256 configuration, twice into the same buffer."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    Kd, M, N = 1152, 512, 768
+    dY, X = torch.randn(Kd, M, generator=g), torch.randn(Kd, N, generator=g)
+    dYd, Xd = dY.to(DEV, BF), X.to(DEV, BF)
+    G = torch.zeros(M, N, device=DEV)
+    with forced(0, 2):
+        ops.gemm(dYd, Xd, True, False, out=G, beta=1.0)
+        ops.gemm(dYd, Xd, True, False, out=G, beta=1.0)
+    want = 2 * (dYd.float().cpu().double().t() @ Xd.float().cpu().double())
+    assert float((G.double().cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_pp_is_the_automatic_choice_for_the_step_shapes():
+    """M = 9216 rows (32 x 288 tokens): the dispatcher takes the ping-pong kernel for the 410M layer products."""
+    ops = _ops()
+    lib = _lib()
+    lib.mafed_gemm_set_variant(701)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn((9216, 1024), device=DEV, generator=g).to(BF)
+    w = torch.randn((4096, 1024), device=DEV, generator=g).to(BF)
+    n0 = lib.mafed_gemm_pp_launches()
+    y = ops.gemm(x, w, False, True)
+    assert lib.mafed_gemm_pp_launches() == n0 + 1
+    lib.mafed_gemm_set_variant(700)
+    y0 = ops.gemm(x, w, False, True)
+    lib.mafed_gemm_set_variant(701)
+    assert float((y.float() - y0.float()).abs().max()) <= 2e-2 * float(y0.float().abs().max())

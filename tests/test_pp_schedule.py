@@ -1,0 +1,38 @@
+"""CPU: the hand-derived tables of the persistent ping-pong GEMM kernel (mafed_amd/csrc/gemm_pp.hip) -- fragment index maps,
+LDS bank conflicts and the counted-vmcnt DMA schedule -- checked by the model in tools/pp_schedule_check.py."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import pp_schedule_check as P  # noqa: E402
+
+CFGS = P.all_cfgs()
+IDS = [f"{c.name}-A{'ks' if c.a_ks else 'kc'}-B{'ks' if c.b_ks else 'kc'}-{'bf16' if c.pair else 'f32'}" for c in CFGS]
+
+
+@pytest.mark.parametrize("c", CFGS, ids=IDS)
+def test_fragment_index_maps(c):
+    P.check_index_maps(c)
+
+
+@pytest.mark.parametrize("c", CFGS, ids=IDS)
+def test_bank_conflicts(c):
+    worst = P.check_bank_conflicts(c)
+    for key, ways in worst.items():
+        # the one accepted conflict: transposing reads of a [k][n] B image whose columns are pair-mapped for 16-byte bf16 stores
+        allowed = 2 if (key == "B:tr" and c.pair) else 1
+        assert ways <= allowed, (key, ways)
+
+
+@pytest.mark.parametrize("c", CFGS, ids=IDS)
+@pytest.mark.parametrize("nst,extra", [(9, 0), (12, 12), (18, 18), (32, 0), (24, 40)])
+def test_dma_schedule_has_no_raw_or_war_hazard(c, nst, extra):
+    assert P.check_schedule(c, nst=nst, extra_epilogue_ops=extra) == []
+
+
+def test_checker_detects_a_loosened_wait(monkeypatch):
+    c = P.Cfg("192x256", False, False, True)
+    monkeypatch.setattr(P, "waits_of", lambda c, post, nst: {0: 6, 2: 5})
+    assert P.check_schedule(c) != []

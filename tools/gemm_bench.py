@@ -10,12 +10,13 @@ dev = "cuda"
 M = int(os.environ.get("GEMM_BENCH_M", "9216"))   # rows = batch x (image + text tokens): 9216 = 32 x 288, 4608 = 16 x 288
 SHAPES = [  # (name, transA, transB, M, N, K, out_dtype)
     ("qkv   NT", False, True, M, 3072, 1024, torch.bfloat16),
-    ("dense NT", False, True, M, 1024, 1024, torch.float32),
+    ("dense NT", False, True, M, 1024, 1024, torch.bfloat16),
     ("fc1   NT", False, True, M, 4096, 1024, torch.bfloat16),
     ("fc2   NT", False, True, M, 1024, 4096, torch.float32),
     ("dfc2  NN", False, False, M, 4096, 1024, torch.bfloat16),
     ("dfc1  NN", False, False, M, 1024, 4096, torch.bfloat16),
     ("dqkv  NN", False, False, M, 1024, 3072, torch.bfloat16),
+    ("dao   NN", False, False, M, 1024, 1024, torch.bfloat16),
     ("wfc2  TN", True, False, 1024, 4096, M, torch.float32),
     ("wfc1  TN", True, False, 4096, 1024, M, torch.float32),
     ("wqkv  TN", True, False, 3072, 1024, M, torch.float32),
@@ -51,6 +52,8 @@ for name, tA, tB, m, n, k, od in SHAPES:
             kw["colsum"] = torch.zeros(n, device=dev)
     elif EPI and name.startswith("fc2"):
         kw = dict(bias=torch.randn(n, device=dev), res1=torch.randn((m, n), device=dev).to(torch.bfloat16), res2=torch.randn((m, n), device=dev))
+    elif EPI and (name.startswith("qkv") or name.startswith("dense")):
+        kw = dict(bias=torch.randn(n, device=dev))
     for v in variants:
         lib.mafed_gemm_set_variant(v)
         out.zero_()
@@ -90,3 +93,4 @@ for name, tA, tB, m, n, k, od in SHAPES:
     print(line + lib_col, flush=True)
 lib.mafed_gemm_set_variant(0)
 lib.mafed_gemm_set_variant(100)
+lib.mafed_gemm_set_variant(701)
