@@ -6,9 +6,11 @@
 // Structure (cdna_hip_programming.md section 5, "256^2 8-phase template", rebuilt from its description for three tile shapes):
 //   * ONE 512-thread workgroup per CU, persistent: a block walks its tiles (tile id = round * grid + slot, XCD-aware order) and the
 //     operand stream never drains -- the LDS-DMA for the first two K-tiles of tile i+1 is issued under the last K-tiles of tile i.
-//   * Two groups of four waves (one wave per SIMD each) run the same program one barrier apart ("ping-pong"): while group 0 issues
-//     its MFMA cluster, group 1 reads fragments from LDS and issues LDS-DMA, and vice versa.  Two raw s_barrier per phase, NPH
-//     phases (12-16 MFMAs each) per 64-deep K-tile.
+//   * Two groups of four waves (one wave per SIMD each) run the same phases half a phase apart ("ping-pong"): between two barriers
+//     every wave reads the NEXT phase's fragments and issues LDS-DMA, then runs the current phase's MFMA cluster; group 1 takes the
+//     phase barrier between the two, group 0 after the cluster, so on every SIMD one wave issues MFMAs while its partner loads.
+//     One raw s_barrier per phase, NPH phases (12-16 MFMAs each) per 64-deep K-tile.  (The two-barriers-per-phase form of the guide's template measured 375-450 cycles
+//     per 192-256-cycle MFMA cluster here: the barrier pair, not the memory system, set the pace.)
 //   * Operands go global -> LDS by global_load_lds_dwordx4 into two K-tile stages; waits are COUNTED (s_waitcnt vmcnt(N), never 0
 //     in the loop): 3-5 phases of DMA stay in flight across the barriers.  Each region of a stage (B, and the A rows of each
 //     phase) is re-filled two phases after its last reader and waited for one phase before its first reader; the tables below
@@ -27,6 +29,22 @@ namespace mafed {
 
 typedef const __attribute__((address_space(4))) PPArgs* pp_args_ptr;
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+#ifdef MAFED_PP_TRACE
+// Tuning builds only (tools/pp_trace.py): one s_memtime stamp per event {0 interval start, 1 epilogue start, 2 epilogue end, 3 next
+// tile ready} of waves 0 and 4 of the first blocks, written to LDS one event late (the stamp has returned by then: no wait in the
+// traced stream) and dumped at the end of the kernel.
+__device__ unsigned long long* g_pp_trace = nullptr;
+extern "C" int mafed_gemm_pp_set_trace(void* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define PP_STAMP(v) asm volatile("s_memtime %0" : "=s"(v))
+constexpr int PP_TRACE_REC = 240, PP_TRACE_BYTES = 2 * PP_TRACE_REC * 2 * 8;
+#else
+#define PP_STAMP(v) do { } while (0)
+constexpr int PP_TRACE_BYTES = 0;
+#endif
 
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
@@ -179,12 +197,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
       dma_set_tile(d_pi != old_pi);
     }
   };
-  auto dma_a = [&](int stage, int i) {
-    __builtin_amdgcn_global_load_lds((glb_void_ptr)(pa + aoff[i]), (lds_void_ptr)(smem + stage * STAGE + a_dst[i]), 16, 0, 0);
+  // LDS-DMA through inline asm: with the builtin hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read_b64_tr_b16 that follows an
+  // LDS-DMA (it cannot tell the transposing read from the DMA's LDS store), which serialised every phase of the dX / dW kernels.
+  // The statement has no VGPR destination (register-safe); M0 = wave-uniform LDS byte address, saved and restored in the same
+  // statement (cdna_hip_programming 5.7); source = uniform 64-bit base in SGPRs + per-lane 32-bit byte offset.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)smem;
+  auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
   };
-  auto dma_b = [&](int stage, int i) {
-    __builtin_amdgcn_global_load_lds((glb_void_ptr)(pb + boff[i]), (lds_void_ptr)(smem + stage * STAGE + b_dst[i]), 16, 0, 0);
-  };
+  auto dma_a = [&](int stage, int i) { dma16(pa, aoff[i], lds0 + stage * STAGE + a_dst[i]); };
+  auto dma_b = [&](int stage, int i) { dma16(pb, boff[i], lds0 + stage * STAGE + b_dst[i]); };
   // issue group g (stream order) of the stream's current K-tile into `stage`
   auto dma_group = [&](int stage, int g) {
     if constexpr (NPH == 4) {          // [B0 B1] [B2 B3] [A0 A1] [A2 A3]
@@ -200,16 +226,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   };
 
   f32x4 acc[NT][MT];
-  bf16x8 fb[2][NT], fa[2][MTP];
+  // fragments are read ONE PHASE AHEAD of the MFMA cluster that consumes them (a wave's own ds_read latency, ~300 cycles with eight
+  // waves reading, was exposed in front of every cluster otherwise): two sets of A fragments by phase parity, two of B by K-tile parity
+  // (NT = 4: one set of B fragments, 32 registers, re-read inside the last cluster of a K-tile as its two k-halves retire)
+  constexpr bool FB2 = NT == 2;
+  bf16x8 fb[FB2 ? 2 : 1][2][NT], fa[2][2][MTP];
+#ifdef MAFED_PP_TRACE
+  const bool trace_on = g_pp_trace != nullptr && blockIdx.x < 4;
+  int trace_n = 0;
+#endif
 
-  auto read_b = [&](const char* st) {
+  auto read_b = [&](const char* st, bf16x8 (&dst)[2][NT], int ks0, int ks1) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = ks0; ks < ks1; ++ks)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if constexpr (!B_KS) {
           const int imm = PAIR ? (32 * (nt >> 1) + 4 * (nt & 1)) * 128 : nt * 2048;
-          fb[ks][nt] = *reinterpret_cast<const bf16x8*>(st + b_rd[ks] + imm);
+          dst[ks][nt] = *reinterpret_cast<const bf16x8*>(st + b_rd[ks] + imm);
         } else {
           const int base = PAIR ? b_rd[nt >> 1] + 8 * (nt & 1) : b_rd[nt];
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(st + base + (32 * ks) * RBB));
@@ -217,63 +251,130 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
           bf16x8 r;
           r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
           r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-          fb[ks][nt] = r;
+          dst[ks][nt] = r;
         }
       }
   };
-  auto read_a = [&](const char* st, int p) {
+  auto read_a = [&](const char* st, int p, bf16x8 (&dst)[2][MTP]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < MTP; ++j) {
         if constexpr (!A_KS) {
-          fa[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_rd[ks] + (p * MTP + j) * 2048);
+          dst[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_rd[ks] + (p * MTP + j) * 2048);
         } else {
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(st + a_rd[j] + p * 8192 + (32 * ks) * 128));
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(st + a_rd[j] + p * 8192 + (32 * ks + 4) * 128));
           bf16x8 r;
           r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
           r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-          fa[ks][j] = r;
+          dst[ks][j] = r;
         }
       }
   };
 
-  // One K-tile: NPH phases of { fragment reads + DMA issue + counted wait | barrier | MFMA cluster | barrier }.
-  // `stage` = parity of the K-tile (compile-time after unrolling by two); `post` = first K-tile after an epilogue.
-  auto ktile = [&](auto stage_c, int kt, int nkt, bool post) {
+  // One K-tile = NPH phases, ONE barrier per phase.  Interval J (between barriers J-1 and J) = { read the fragments of phase J+1 into
+  // the other fragment set; issue DMA; counted wait; MFMA cluster of phase J }: nothing in an interval waits for an LDS or a memory
+  // round trip of its own.  A region (B, or the A rows of one phase) whose fragments are read in interval J-1 and consumed in
+  // interval J is re-filled from interval J+1 on; data covered by a counted wait in interval j is read from interval j+1 on
+  // (tools/pp_schedule_check.py).  DMA issue groups per K-tile, in stream order:
+  //   NPH = 3: [B0 B1 B2] [B3 A0] [A1 A2]   slot 0: group 2 of K-tile kt+1 | slot 1: group 0 of kt+2, vmcnt(5) | slot 2: group 1 of kt+2, vmcnt(5)
+  //   NPH = 4: [B0 B1] [B2 B3] [A0 A1] [A2 A3]   slot 0: group 3 of kt+1, vmcnt(8) | slot 1: group 0 of kt+2 | slot 2: group 1, vmcnt(6) | slot 3: group 2
+  // `stage` = parity of the K-tile (compile-time after unrolling by two); `post` = first K-tile after an epilogue (its stores sit
+  // in the VMEM queue between the DMAs: the waits that still target a DMA issued before them count NST more operations).
+  // STAG: group 1 takes the barrier between its loads and its MFMA cluster (half a phase behind group 0; MI355X_MICROARCH "Two
+  // waves per SIMD" item 9); it then retires the PREVIOUS interval's fragment reads with a counted lgkmcnt before that barrier,
+  // which is where group 0 retires them (before its cluster).
+#ifdef MAFED_PP_TRACE
+  unsigned long long ts_cur = 0;
+  int ts_tag = -1;
+  auto trace_event = [&](int tag) {
+    const unsigned long long prev = ts_cur;
+    const int prev_tag = ts_tag;
+    PP_STAMP(ts_cur);
+    ts_tag = tag;
+    if (trace_on && (wave & 3) == 0 && lane == 0 && prev_tag >= 0 && trace_n < PP_TRACE_REC) {
+      unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE + 2048) + (grp * PP_TRACE_REC + trace_n) * 2;
+      tr[0] = prev; tr[1] = (unsigned long long)prev_tag;
+    }
+    if (prev_tag >= 0) ++trace_n;
+  };
+#else
+  auto trace_event = [&](int) {};
+#endif
+#ifndef MAFED_PP_STAGGER
+#define MAFED_PP_STAGGER 1
+#endif
+  constexpr bool STAG = MAFED_PP_STAGGER != 0 && FB2;   // (the in-cluster B refresh of NT = 4 reads B after the barrier a staggered group 1 would take: uniform program there)
+  constexpr int RD_A = (A_KS ? 4 : 2) * MTP, RD_B = (B_KS ? 4 : 2) * NT;   // LDS read instructions of one phase's A / one K-tile's B fragments
+  auto seg_load = [&](auto stage_c, int p, int set, bool post) {
     constexpr int S = decltype(stage_c)::value;
-    (void)kt; (void)nkt;
-    const char* st = smem + S * STAGE;
+    if (p + 1 < NPH) {
+      read_a(smem + S * STAGE, p + 1, fa[set ^ 1]);
+    } else {
+      if constexpr (FB2) read_b(smem + (S ^ 1) * STAGE, fb[S ^ 1], 0, 2);
+      read_a(smem + (S ^ 1) * STAGE, 0, fa[set ^ 1]);
+    }
+    if constexpr (NPH == 4) {
+      if (p == 0) dma_group(S ^ 1, 3);
+      if (p == 1) { dma_advance(); dma_group(S, 0); }
+      if (p == 2) dma_group(S, 1);
+      if (p == 3) dma_group(S, 2);
+    } else {
+      if (p == 0) dma_group(S ^ 1, 2);
+      if (p == 1) { dma_advance(); dma_group(S, 0); }
+      if (p == 2) dma_group(S, 1);
+    }
+    if constexpr (NPH == 4) {
+      if (p == 0) { if (post) pp_wait_vmcnt<(8 + NST > 63 ? 63 : 8 + NST)>(); else pp_wait_vmcnt<8>(); }
+      if (p == 2) { if (post) pp_wait_vmcnt<(6 + NST > 63 ? 63 : 6 + NST)>(); else pp_wait_vmcnt<6>(); }
+    } else {
+      if (p == 1) { if (post) pp_wait_vmcnt<(5 + NST > 63 ? 63 : 5 + NST)>(); else pp_wait_vmcnt<5>(); }
+      if (p == 2) pp_wait_vmcnt<5>();
+    }
+  };
+  auto seg_mfma = [&](int S, int p, int set) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < MTP; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt][p * MTP + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[FB2 ? S : 0][ks][nt], fa[set][ks][j], acc[nt][p * MTP + j], 0, 0, 0);
+      if constexpr (!FB2) {
+        // last cluster of the K-tile: this k-half of the B fragments is dead, fetch the next K-tile's into the same registers
+        if (p == NPH - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          read_b(smem + (S ^ 1) * STAGE, fb[0], ks, ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // (one lambda instance per group: a wave-uniform branch INSIDE the phase loop makes the register allocator join all accumulators
+  //  at every phase and spill; the two groups' loops meet only at the epilogue)
+  auto ktile = [&](auto stage_c, auto grp_c, bool post) {
+    constexpr int S = decltype(stage_c)::value, GRP = decltype(grp_c)::value;
 #pragma unroll
     for (int p = 0; p < NPH; ++p) {
+      const int set = (S * NPH + p) & 1;
       __builtin_amdgcn_sched_barrier(0);
-      if (p == 0) read_b(st);
-      read_a(st, p);
-      // DMA: slots 0, 1 finish K-tile kt+1 (the other stage), slots >= 2 start K-tile kt+2 (this stage: regions already read)
-      if (p == 2) dma_advance();
-      if (p < 2) dma_group(S ^ 1, NPH - 2 + p);
-      else dma_group(S, p - 2);
-      if constexpr (NPH == 4) {
-        if (p == 1) { if (post) pp_wait_vmcnt<(8 + NST > 63 ? 63 : 8 + NST)>(); else pp_wait_vmcnt<8>(); }
-        if (p == 3) pp_wait_vmcnt<6>();
-      } else {
-        if (p == 0) { if (post) pp_wait_vmcnt<(5 + NST > 63 ? 63 : 5 + NST)>(); else pp_wait_vmcnt<5>(); }
-        if (p == 2) pp_wait_vmcnt<5>();
+      trace_event(0);
+      seg_load(stage_c, p, set, post);
+      if constexpr (STAG && GRP == 1) {
+        // the reads of the previous interval (consumed by the cluster below, after the barrier) retire here: only this interval's remain
+        constexpr int NEW_B = RD_B, NEW_A = RD_A;
+        if (p + 1 < NPH) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NEW_A > 15 ? 15 : NEW_A) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NEW_A + NEW_B > 15 ? 15 : NEW_A + NEW_B) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
       }
-      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < MTP; ++j)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[nt][p * MTP + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][nt], fa[ks][j], acc[nt][p * MTP + j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      seg_mfma(S, p, set);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(STAG && GRP == 1)) __builtin_amdgcn_s_barrier();
     }
   };
 
@@ -456,15 +557,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   decode(id, pi, tm, tn);
   d_pi = pi; d_tm = tm; d_tn = tn;
   dma_set_tile(true);
-  // prologue: K-tile 0 (all groups) into stage 0, the first NPH - 2 groups of K-tile 1 into stage 1, as the steady state would have
+  // prologue = "interval -1": K-tile 0 (all groups) into stage 0 and the first NPH - 1 groups of K-tile 1 into stage 1, as the steady
+  // state would have by now; every piece of K-tile 0 that phases 0 and 1 read has landed once only those of K-tile 1 (and, NPH = 4,
+  // K-tile 0's last group) remain; then phase 0's fragments
 #pragma unroll
   for (int g = 0; g < NPH; ++g) dma_group(0, g);
   dma_advance();
 #pragma unroll
-  for (int g = 0; g < NPH - 2; ++g) dma_group(1, g);
-  // B and the phase-0 A rows of K-tile 0 (groups 0 .. NPH-2) have landed once at most (last group of K-tile 0 + K-tile 1's) remain
-  if constexpr (NPH == 4) pp_wait_vmcnt<6>(); else pp_wait_vmcnt<5>();
+  for (int g = 0; g < NPH - 1; ++g) dma_group(1, g);
+  if constexpr (NPH == 4) pp_wait_vmcnt<8>(); else pp_wait_vmcnt<5>();
   __builtin_amdgcn_s_barrier();
+  read_b(smem, fb[0], 0, 2);
+  read_a(smem, 0, fa[0]);
   bool first = true;
   while (true) {
     const int nkt = args->p[pi].nkt;
@@ -472,18 +576,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0 inside the K loop
-    for (int kt = 0; kt < nkt; kt += 2) {
-      ktile(std::integral_constant<int, 0>{}, kt, nkt, !first && kt == 0);
-      ktile(std::integral_constant<int, 1>{}, kt + 1, nkt, false);
+    if (grp == 0) {
+      for (int kt = 0; kt < nkt; kt += 2) {
+        ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, !first && kt == 0);
+        ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, false);
+      }
+    } else {
+      for (int kt = 0; kt < nkt; kt += 2) {
+        ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, !first && kt == 0);
+        ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, false);
+      }
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run their epilogues side by side
+    trace_event(1);
     epilogue(pi, tm, tn);
+    trace_event(2);
     first = false;
     id += G;
     if (id >= ntiles) break;
     decode(id, pi, tm, tn);
+    trace_event(3);
   }
+  trace_event(3);
+#ifdef MAFED_PP_TRACE
+  if (trace_on && (wave & 3) == 0 && lane == 0) {
+    const unsigned long long* tr = reinterpret_cast<const unsigned long long*>(smem + 2 * STAGE + 2048) + grp * PP_TRACE_REC * 2;
+    unsigned long long* dst = g_pp_trace + ((int64_t)blockIdx.x * 2 + grp) * (PP_TRACE_REC * 2 + 1);
+    const int n = trace_n < PP_TRACE_REC ? trace_n : PP_TRACE_REC;
+    dst[0] = n;
+    for (int i = 0; i < n * 2; ++i) dst[1 + i] = tr[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -492,7 +614,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
 template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT>
 static int pp_launch_t(const PPArgs& a, double flops, hipStream_t st) {
   constexpr int TM = WM * MT * 16, TN = WN * NT * 16;
-  constexpr int LDS = 2 * (TM + TN) * 128 + 2048;
+  constexpr int LDS = 2 * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES;
   auto kfn = gemm_pp_kernel<WM, WN, MT, NT, A_KS, B_KS, CT>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -34,5 +34,5 @@ def test_dma_schedule_has_no_raw_or_war_hazard(c, nst, extra):
 
 def test_checker_detects_a_loosened_wait(monkeypatch):
     c = P.Cfg("192x256", False, False, True)
-    monkeypatch.setattr(P, "waits_of", lambda c, post, nst: {0: 6, 2: 5})
+    monkeypatch.setattr(P, "waits_of", lambda c, post, nst: {1: 6, 2: 5})
     assert P.check_schedule(c) != []

@@ -254,10 +254,13 @@ def check_bank_conflicts(c):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# 3. the DMA schedule.  Barrier intervals (BI): group 0 runs phase f as [L at 2f][M at 2f+1], group 1 one interval later.
-#    Per wave the VMEM queue is in issue order; a counted wait vmcnt(N) in an L segment guarantees everything but that wave's
-#    N youngest operations.  Data is readable by any wave in a BI strictly after the BI of EVERY issuing wave's covering wait;
-#    a region may be re-filled (DMA issued) from 2 BIs after the BI in which its last reader issued its ds_reads.
+# 3. the DMA schedule.  One barrier per phase; interval J = the span between barriers J-1 and J.  In interval J every wave reads
+#    the fragments of phase J+1 (prefetch, double-buffered), issues DMA, takes its counted wait and runs the MFMA cluster of phase
+#    J (a staggered group 1 runs that cluster after barrier J, but retires the reads of phase J before it, like group 0).  So the
+#    fragments of phase P are read in interval P-1 and have retired by barrier P: the region may be re-filled (DMA issued) from
+#    interval P+1 on.  Per wave the VMEM queue is in issue order; a counted wait vmcnt(N) guarantees everything but that wave's
+#    N youngest operations.  Data is readable by any wave in an interval strictly after the interval of EVERY issuing wave's
+#    covering wait.
 # ---------------------------------------------------------------------------------------------------------------------
 def groups_of(c):
     """Issue groups in stream order: lists of (kind, index) per wave and K-tile."""
@@ -281,21 +284,26 @@ def piece_regions(c, wave, kind, i):
 def waits_of(c, post, nst):
     """vmcnt immediates after the issue of phase slot p (None = no wait)."""
     if c.NPH == 4:
-        return {1: min(63, 8 + nst) if post else 8, 3: 6}
-    return {0: min(63, 5 + nst) if post else 5, 2: 5}
+        return {0: min(63, 8 + nst) if post else 8, 2: min(63, 6 + nst) if post else 6}
+    return {1: min(63, 5 + nst) if post else 5, 2: 5}
+
+
+def issue_of(c, p):
+    """(K-tile offset relative to the computing K-tile, issue group) of phase slot p."""
+    if c.NPH == 4:
+        return [(1, 3), (2, 0), (2, 1), (2, 2)][p]
+    return [(1, 2), (2, 0), (2, 1)][p]
 
 
 def check_schedule(c, nkt=4, ntiles=3, nst=9, extra_epilogue_ops=7):
     NPH = c.NPH
     grps = groups_of(c)
     # global stream K-tile index s = tile * nkt + kt; stage = s & 1
-    issue_bi = {}     # (wave, s, kind, i) -> BI of issue
-    cover_bi = {}     # (wave, s, kind, i) -> BI of the first wait that guarantees it
-    read_bi = {}      # (group, s, region) -> BI of the read
+    issue_bi = {}     # (wave, s, kind, i) -> interval of issue
+    cover_bi = {}     # (wave, s, kind, i) -> interval of the first wait that guarantees it
+    read_bi = {}      # (s, region) -> interval in which its fragments are read
     for wave in range(8):
-        g = wave >> 2
         queue = []    # issue order: entries are DMA keys or ('st',)
-        bi = 0        # current barrier interval of this wave's L segment bookkeeping
 
         def do_wait(n, at_bi):
             done = queue[:len(queue) - n] if n < len(queue) else []
@@ -309,13 +317,12 @@ def check_schedule(c, nkt=4, ntiles=3, nst=9, extra_epilogue_ops=7):
                 queue.append(key)
                 issue_bi[key] = at_bi
 
-        # prologue (BI -1: before the first common barrier)
+        # prologue ("interval -1"): K-tile 0 complete, NPH - 1 groups of K-tile 1, one counted wait, a barrier, phase 0's fragment reads
         for gi in range(NPH):
-            issue(0, gi, -1)
-        for gi in range(NPH - 2):
-            issue(1, gi, -1)
-        do_wait(6 if NPH == 4 else 5, -1)
-        # tile t starts at barrier interval base(t); the extra un-stagger / re-stagger barriers add one interval per tile
+            issue(0, gi, -2)
+        for gi in range(NPH - 1):
+            issue(1, gi, -2)
+        do_wait(8 if NPH == 4 else 5, -2)
         base = 0
         for t in range(ntiles):
             for kt in range(nkt):
@@ -323,39 +330,36 @@ def check_schedule(c, nkt=4, ntiles=3, nst=9, extra_epilogue_ops=7):
                 post = t > 0 and kt == 0
                 w = waits_of(c, post, nst)
                 for p in range(NPH):
-                    f_bi = base + 2 * (kt * NPH + p) + g          # this wave's L segment
+                    f_bi = base + kt * NPH + p                    # this interval: cluster of phase p, reads of phase p + 1
                     regs = [("A", p)] + ([("B",)] if p == 0 else [])
                     for r in regs:
-                        read_bi[(g, s, r)] = f_bi
-                    if p < 2:
-                        issue(s + 1, NPH - 2 + p, f_bi)
-                    else:
-                        issue(s + 2, p - 2, f_bi)
+                        read_bi[(s, r)] = f_bi - 1                # ... whose fragments were read one interval earlier
+                    dk, gi = issue_of(c, p)
+                    issue(s + dk, gi, f_bi)
                     if p in w:
                         do_wait(w[p], f_bi)
             # epilogue: its loads are waited for inside it; at least nst stores stay queued
             for _ in range(nst + extra_epilogue_ops):
                 queue.append(("st",))
-            base += 2 * nkt * NPH + 1
+            base += nkt * NPH
     errors = []
     total_s = ntiles * nkt
-    for (g, s, r), rb in read_bi.items():
+    for (s, r), rb in read_bi.items():
         for wave in range(8):
             for gi, grp in enumerate(grps):
                 for kind, i in grp:
                     if r in piece_regions(c, wave, kind, i) or (r == ("B",) and kind == "B"):
                         key = (wave, s, kind, i)
                         if key not in cover_bi or cover_bi[key] >= rb:
-                            errors.append(("RAW", c.name, "group", g, "ktile", s, r, "wave", wave, kind, i, cover_bi.get(key), rb))
+                            errors.append(("RAW", c.name, "ktile", s, r, "wave", wave, kind, i, cover_bi.get(key), rb))
     for key, ib in issue_bi.items():
         wave, s, kind, i = key
         if s < 2 or s >= total_s:
             continue
         for r in piece_regions(c, wave, kind, i):
-            for g in range(2):
-                rb = read_bi.get((g, s - 2, r))
-                if rb is not None and ib < rb + 2:
-                    errors.append(("WAR", c.name, key, "issued", ib, "last read", rb, "group", g))
+            rb = read_bi.get((s - 2, r))
+            if rb is not None and ib < rb + 2:   # read in interval rb, retired by barrier rb + 1, re-fill from interval rb + 2
+                errors.append(("WAR", c.name, key, "issued", ib, "fragments read in", rb))
     return errors
 
 
