@@ -712,7 +712,7 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
     Ms[i] = q.M; Ns[i] = q.N; Ks[i] = q.K;
     if (one) {
       // one configuration for the whole group: the one the first problem picks must tile the others too
-      const int c = gemm_pp_pick(a_ks, b_ks, c_dtype, q.M, q.N, q.K, i == 0 ? g_gemm_pp_force : cfg);
+      const int c = gemm_pp_pick(a_ks, b_ks, c_dtype, q.M, q.N, q.K, q.lda, q.ldb, i == 0 ? g_gemm_pp_force : cfg);
       if (i == 0) cfg = c;
       one = c != PP_NONE && c == cfg;
     }
@@ -782,7 +782,13 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
   if ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0) {
     PPProblem pr;
     if (pp_fill_problem(pr, a_ks, b_ks, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, epi, colsum)) {
-      const int pcfg = gemm_pp_pick(a_ks, b_ks, c_dtype, M, N, K, g_gemm_pp_force);
+      int pcfg = gemm_pp_pick(a_ks, b_ks, c_dtype, M, N, K, lda, ldb, g_gemm_pp_force);
+      if (pcfg != PP_NONE && g_gemm_pp_force < 0) {
+        // one persistent block per CU: a tile count that leaves the last round of the 256 CUs mostly empty (a single weight gradient:
+        // 128 tiles) is the 128 x 128 kernel's job, or that of a grouped launch
+        const int64_t tiles = (M / (pcfg == PP_128x256 ? 128 : 144)) * (N / 256), rounds = (tiles + 255) / 256;
+        if (tiles * 100 < rounds * 256 * 85) pcfg = PP_NONE;
+      }
       if (pcfg != PP_NONE) {
         rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st);
         if (rc != MAFED_OK) return rc;

@@ -3,23 +3,30 @@
 // Replaces, for the tile-aligned shapes of the training step, every nn.Linear forward / dX / dW product of
 // transformers/models/gpt_neox/modeling_gpt_neox.py:38-49,192-236 (the reference runs them through torch.matmul under bf16 autocast).
 //
-// Structure (cdna_hip_programming.md section 5, "256^2 8-phase template", rebuilt from its description for three tile shapes):
+// Structure (cdna_hip_programming.md section 5, "256^2 8-phase template", rebuilt from its description and then changed where the
+// in-kernel event trace of this file, tools/pp_trace.py, showed a stall):
 //   * ONE 512-thread workgroup per CU, persistent: a block walks its tiles (tile id = round * grid + slot, XCD-aware order) and the
-//     operand stream never drains -- the LDS-DMA for the first two K-tiles of tile i+1 is issued under the last K-tiles of tile i.
-//   * Two groups of four waves (one wave per SIMD each) run the same phases half a phase apart ("ping-pong"): between two barriers
-//     every wave reads the NEXT phase's fragments and issues LDS-DMA, then runs the current phase's MFMA cluster; group 1 takes the
-//     phase barrier between the two, group 0 after the cluster, so on every SIMD one wave issues MFMAs while its partner loads.
-//     One raw s_barrier per phase, NPH phases (12-16 MFMAs each) per 64-deep K-tile.  (The two-barriers-per-phase form of the guide's template measured 375-450 cycles
-//     per 192-256-cycle MFMA cluster here: the barrier pair, not the memory system, set the pace.)
-//   * Operands go global -> LDS by global_load_lds_dwordx4 into two K-tile stages; waits are COUNTED (s_waitcnt vmcnt(N), never 0
-//     in the loop): 3-5 phases of DMA stay in flight across the barriers.  Each region of a stage (B, and the A rows of each
-//     phase) is re-filled two phases after its last reader and waited for one phase before its first reader; the tables below
-//     were derived by hand and are checked by tools/pp_schedule_check.py (RAW / WAR over both groups' barrier intervals).
+//     operand stream never drains -- the LDS-DMA for the first K-tiles of tile i+1 is issued under the last K-tiles of tile i.
+//   * 1 x 8 waves; two groups of four (one wave per SIMD each) run the same phases half a phase apart: in every interval between
+//     two barriers a wave reads the NEXT phase's fragments (double-buffered), issues LDS-DMA, takes a counted wait and runs the
+//     current phase's MFMA cluster; group 1 takes the phase barrier between the loads and the cluster, group 0 after the cluster,
+//     so on every SIMD one wave issues MFMAs while its partner loads.  One raw s_barrier per phase, NPH phases (12-16 MFMAs each)
+//     per 64-deep K-tile.  Measured steps that led here: two barriers per phase (the guide's form) 375-450 cycles per 192-256-cycle
+//     cluster; fragments read in the phase that consumes them: ~300 cycles of ds_read latency exposed before every cluster.
+//   * Operands go global -> LDS by global_load_lds_dwordx4 into a ring of K-tile stages; waits are COUNTED (s_waitcnt vmcnt(N), never 0
+//     in the loop): 2-3 phases of DMA stay in flight across the barriers.  Each region of a stage (B, and the A rows of each phase)
+//     is re-filled one interval after the barrier that retires its readers and waited for one interval before its first reader;
+//     the tables are checked by tools/pp_schedule_check.py (index maps, bank conflicts, RAW / WAR of the schedule).
+//     The DMA is issued through inline asm: hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read_b64_tr_b16 that follows an
+//     LDS-DMA builtin, and a spilled register anywhere in the kernel puts a vmcnt(0) for its scratch reload into the loop.
 //   * fragment-to-column map chosen so that the accumulators are stored straight from registers in 64-byte row segments
-//     (bf16 C: a lane owns 8 consecutive columns of a row over two fragments), no LDS round trip in the epilogue.
-//   * tile shapes: 256x256 (2x4 waves of 128x64; dW), 192x256 (2x4 waves of 96x64; N = 4096), 144x256 (1x8 waves of 144x32;
-//     N = 1024 / 3072): each makes the tile count of the M = 9216 step GEMMs a whole number of rounds of 256 CUs.
+//     (bf16 C: a lane owns 8 consecutive columns of a row over its two fragments), no LDS round trip in the epilogue.
+//   * tile shapes: 144 x 256 (wave tile 144 x 32, three phases, two stages: every M = 9216 product of the step is a whole number
+//     of rounds of 256 CUs -- N = 1024 / 3072 / 4096 -> 256 / 768 / 1024 tiles) and 128 x 256 (wave tile 128 x 32, two phases,
+//     three stages: the weight gradients, whose operands are both reduction-major).
 //   * grouped launches: up to 16 problems (same layouts / output type) share one grid; the tile space is their concatenation.
+//   * problem fields live in SGPRs and are re-read from the kernarg table only when the problem changes (a scalar load is a ~1 us
+//     round trip; a chain of them in front of every tile cost a K = 1024 tile a quarter of its time).
 #include <type_traits>
 
 #include "gemm_pp.h"
@@ -53,49 +60,49 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
 }
 
 __device__ __forceinline__ int pp_f2(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }                 // [k][64] image: 32-byte chunk XOR
-__device__ __forceinline__ int pp_fpair(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }       // KC image read with pair-mapped rows
 
-template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT>
+// MT x NT fragments of 16 x 16 per wave (wave tile MT*16 x NT*16, block tile MT*16 x 8*NT*16), NPH phases per K-tile, NSTG stages.
+template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16;
-  constexpr int NPH = (MT == 8) ? 4 : 3;        // phases per K-tile
+  constexpr int TM = MT * 16, TN = 8 * NT * 16;
   constexpr int MTP = MT / NPH;                 // A row fragments per phase
-  static_assert(WM * WN == 8 && MT % NPH == 0 && TN == 256, "8 waves, 256 columns");
+  static_assert(MT % NPH == 0 && TN == 256 && NT == 2, "1 x 8 waves of MT*16 x 32, 256 columns");
+  static_assert((NPH == 3 && NSTG == 2) || (NPH == 2 && NSTG == 3), "DMA schedules: three phases over two stages, two phases over three");
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr bool PAIR = sizeof(CT) == 2;        // bf16 C: lane owns 8 consecutive columns over a fragment pair
-  constexpr int A_PW = (WM == 2) ? NPH : 3;     // A pieces (1 KiB DMA instructions) per wave per K-tile
+  constexpr bool PAIR = sizeof(CT) == 2;        // bf16 C: lane owns 8 consecutive columns over its fragment pair
+  static_assert(!A_KS || MTP == 4, "regional [k][64] A image: four fragments per phase region");
+  constexpr int A_PW = A_KS ? NPH : (TM + 63) / 64;   // A pieces (1 KiB DMA instructions) per wave per K-tile
   constexpr int B_PW = 4;
+  static_assert(A_PW + B_PW == (NPH == 3 ? 7 : 6), "issue groups: 3+2+2 (3+2+1 for waves 2..7 of a 144-row tile) / 3+3 pieces per wave");
   constexpr int RBB = TN * 2;                   // bytes per k-row of the [k][TN] image
-  static_assert(!A_KS || (WM == 2 && MTP == 2), "regional [k][64] A image: 2 x 2 fragments per phase region");
-  static_assert(WM == 2 || (WM == 1 && MT == 9), "piece tables: 2 x 4 waves, or 1 x 8 waves of 144 rows");
   constexpr int NPAIR = NT / 2;
   constexpr int NST = PAIR ? MT * NPAIR : MT * NT;   // C stores per wave per tile: lower bound of the epilogue's VMEM operations
-  constexpr int NB_RD = B_KS ? (PAIR ? NPAIR : NT) : 2;
+  constexpr int NA_RD = A_KS ? MTP : 2, NB_RD = B_KS ? (PAIR ? NPAIR : NT) : 2, NVB = (PAIR && !B_KS) ? 4 : 2;
   (void)args_by_value;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   pp_args_ptr args = (pp_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wm = wave / WN, wn = wave % WN;
+  const int grp = wave >> 2;
   const int li = lane & 15, q4 = lane >> 4;
 
   // ---- fragment read offsets (bytes from the start of a stage; the rest are compile-time immediates) --------------------------
-  int a_rd[2], b_rd[NB_RD];
+  int a_rd[NA_RD], b_rd[NB_RD];
   if constexpr (!A_KS) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_rd[ks] = (wm * MT * 16 + li) * 128 + (((ks * 4 + q4) ^ ((li >> 1) & 7)) << 4);
+    for (int ks = 0; ks < 2; ++ks) a_rd[ks] = li * 128 + (((ks * 4 + q4) ^ ((li >> 1) & 7)) << 4);
   } else {
     const int F2 = ((li >> 3) & 1) | ((q4 & 1) << 1);
 #pragma unroll
-    for (int jf = 0; jf < 2; ++jf) a_rd[jf] = (8 * q4 + (li >> 2)) * 128 + (((wm * 2 + jf) ^ F2) << 5) + (li & 3) * 8;
+    for (int jf = 0; jf < MTP; ++jf) a_rd[jf] = (8 * q4 + (li >> 2)) * 128 + ((jf ^ F2) << 5) + (li & 3) * 8;
   }
   if constexpr (!B_KS) {
     if constexpr (!PAIR) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) b_rd[ks] = A_BYTES + (wn * NT * 16 + li) * 128 + (((ks * 4 + q4) ^ ((li >> 1) & 7)) << 4);
+      for (int ks = 0; ks < 2; ++ks) b_rd[ks] = A_BYTES + (wave * NT * 16 + li) * 128 + (((ks * 4 + q4) ^ ((li >> 1) & 7)) << 4);
     } else {
-      const int rowb = wn * NT * 16 + 8 * (li >> 2) + (li & 3);
+      const int rowb = wave * NT * 16 + 8 * (li >> 2) + (li & 3);
       const int fp = ((li >> 1) & 1) | (((li >> 2) & 3) << 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) b_rd[ks] = A_BYTES + rowb * 128 + (((ks * 4 + q4) ^ fp) << 4);
@@ -105,47 +112,55 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     const int kq = (8 * q4 + (li >> 2)) * RBB;
     if constexpr (!PAIR) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b_rd[nt] = A_BYTES + kq + (((wn * NT + nt) ^ F) << 5) + (li & 3) * 8;
+      for (int nt = 0; nt < NT; ++nt) b_rd[nt] = A_BYTES + kq + (((wave * NT + nt) ^ F) << 5) + (li & 3) * 8;
     } else {
 #pragma unroll
-      for (int pr = 0; pr < NPAIR; ++pr) b_rd[pr] = A_BYTES + kq + (((wn * NT + 2 * pr + ((li & 3) >> 1)) ^ F) << 5) + 16 * (li & 1);
+      for (int pr = 0; pr < NPAIR; ++pr) b_rd[pr] = A_BYTES + kq + (((wave * NT + 2 * pr + ((li & 3) >> 1)) ^ F) << 5) + 16 * (li & 1);
     }
   }
 
-  // ---- this wave's DMA pieces: LDS destination inside a stage (wave-uniform) and per-lane source byte offset -------------------
-  int a_dst[A_PW], b_dst[B_PW];
-  uint32_t aoff[A_PW], boff[B_PW];
-  auto set_offsets = [&](int64_t lda, int64_t ldb) {
+  // ---- this wave's DMA pieces ------------------------------------------------------------------------------------------------------
+  // source address = operand K-tile base (SGPR pair) + piece offset (scalar, a multiple of the leading dimension) + per-lane offset.
+  // The per-lane part is the same for every A piece of a wave (their row index has one parity) and has two (four: pair-mapped KC
+  // image) variants over its B pieces, so a change of leading dimension (grouped launch) recomputes 3 - 5 registers, in registers.
+  int a_dst[A_PW], b_dst[B_PW];           // LDS destination inside a stage (wave-uniform)
+  uint32_t a_so[A_PW], b_so[B_PW];        // scalar byte offset of the piece inside the operand K-tile
+  uint32_t va, vb[NVB];
+  auto set_offsets = [&](uint32_t lda, uint32_t ldb) {
+    const int r = lane >> 3, ph = lane & 7;
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
       if constexpr (!A_KS) {
-        int pj;
-        if constexpr (WM == 2) pj = (wave >> 2) * (MT * 2) + i * 4 + (wave & 3);   // group i's rows of this wave's half
-        else pj = i == 0 ? wave : (i == 1 ? wave + 8 : 16 + (wave & 1));           // 18 pieces over 8 waves (6 duplicates)
+        const int pj = i < TM / 64 ? wave + 8 * i : 16 + (wave & 1);   // 144 rows: 18 pieces, the last two by waves 0 and 1 (ODD = wave < 2)
         a_dst[i] = pj * 1024;
-        const int row = 8 * pj + (lane >> 3);
-        aoff[i] = (uint32_t)(row * lda * 2) + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        a_so[i] = (uint32_t)(8 * pj) * lda * 2u;
       } else {
         a_dst[i] = i * 8192 + wave * 1024;
-        const int k = 8 * wave + (lane >> 3), ph = lane & 7;
-        const int l32 = (ph >> 1) ^ pp_f2(k);
-        const int row = (l32 >> 1) * (MT * 16) + (i * 2 + (l32 & 1)) * 16 + (ph & 1) * 8;
-        aoff[i] = (uint32_t)((k * lda + row) * 2);
+        a_so[i] = (uint32_t)(8 * wave) * lda * 2u + (uint32_t)i * 128u;
       }
+    }
+    if constexpr (!A_KS) {
+      va = (uint32_t)r * lda * 2u + (uint32_t)((ph ^ ((r >> 1) | ((wave & 1) << 2))) << 4);
+    } else {
+      const int l32 = (ph >> 1) ^ (((r >> 1) & 1) | ((wave & 1) << 1));   // f2(k), k = 8 * wave + r
+      va = (uint32_t)r * lda * 2u + (uint32_t)(l32 * 16 + (ph & 1) * 8) * 2u;
     }
 #pragma unroll
     for (int i = 0; i < B_PW; ++i) {
       const int pj = 4 * wave + i;
       b_dst[i] = A_BYTES + pj * 1024;
+      if constexpr (!B_KS) b_so[i] = (uint32_t)(8 * pj) * ldb * 2u;
+      else b_so[i] = (uint32_t)(2 * pj) * ldb * 2u;
+    }
+#pragma unroll
+    for (int v = 0; v < NVB; ++v) {
       if constexpr (!B_KS) {
-        const int row = 8 * pj + (lane >> 3);
-        const int f = PAIR ? pp_fpair(row) : ((row >> 1) & 7);
-        boff[i] = (uint32_t)(row * ldb * 2) + (uint32_t)(((lane & 7) ^ f) << 4);
+        const int f = PAIR ? (((r >> 1) & 1) | (v << 1)) : ((r >> 1) | (v << 2));   // row = 8 * (4 * wave + i) + r, v = i & 3 / i & 1
+        vb[v] = (uint32_t)r * ldb * 2u + (uint32_t)((ph ^ f) << 4);
       } else {
-        const int pb = pj * 1024 + lane * 16;
-        const int k = pb / RBB, within = pb % RBB;
-        const int l32 = (within >> 5) ^ ks_f(k);
-        boff[i] = (uint32_t)((k * ldb + l32 * 16 + ((within >> 4) & 1) * 8) * 2);
+        const int kl = 2 * v + (lane >> 5);                                          // k = 8 * wave + 2 * i + (lane >> 5), v = i & 1
+        const int l32 = ((lane & 31) >> 1) ^ ((kl & 3) | ((wave & 1) << 2));
+        vb[v] = (uint32_t)(lane >> 5) * ldb * 2u + (uint32_t)(l32 * 16 + (lane & 1) * 8) * 2u;
       }
     }
   };
@@ -157,88 +172,124 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     const int b = (int)blockIdx.x, q = G >> 3, r = G & 7, x = b & 7;   // bijective XCD remap (cdna_hip_programming T1)
     slot = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
-  auto decode = [&](int id, int& pi, int& tm, int& tn) {
-    pi = 0;
-    for (int j = 1; j < args->nprobs; ++j)
-      if (id >= args->p[j].tile_begin) pi = j;
-    const int lt = id - args->p[pi].tile_begin;
-    const int tiles_m = args->p[pi].tiles_m, tiles_n = args->p[pi].tiles_n, GM = args->group_m;
-    const int gsz = GM * tiles_n, group = lt / gsz, first_m = group * GM;
-    const int gm = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+  // Problem fields live in SGPRs and are re-read from the kernarg table only when a tile belongs to another problem.
+  // `dq` = the problem of the DMA stream's tile, `cq` = the problem of the tile being computed.
+  struct DmaProb { const char* A; const char* B; uint32_t lda, ldb; int nkt, tiles_m, tiles_n, tile_begin; } dq;
+  struct EpiProb { void* C; const float* bias; void* aux; const void* res1; const float* res2; float* colsum; int64_t ldc; float beta; int mode, res1_bf16, nkt; } cq;
+  const int GM = args->group_m, nprobs = args->nprobs;
+  auto load_dq = [&](int pi) {
+    dq.A = reinterpret_cast<const char*>(args->p[pi].A); dq.B = reinterpret_cast<const char*>(args->p[pi].B);
+    dq.lda = (uint32_t)args->p[pi].lda; dq.ldb = (uint32_t)args->p[pi].ldb; dq.nkt = args->p[pi].nkt;
+    dq.tiles_m = args->p[pi].tiles_m; dq.tiles_n = args->p[pi].tiles_n; dq.tile_begin = args->p[pi].tile_begin;
+  };
+  auto load_cq = [&](int pi) {
+    cq.C = args->p[pi].C; cq.bias = args->p[pi].bias; cq.aux = args->p[pi].aux; cq.res1 = args->p[pi].res1; cq.res2 = args->p[pi].res2;
+    cq.colsum = args->p[pi].colsum; cq.ldc = args->p[pi].ldc; cq.beta = args->p[pi].beta; cq.mode = args->p[pi].mode;
+    cq.res1_bf16 = args->p[pi].res1_bf16; cq.nkt = args->p[pi].nkt;
+  };
+  // tile id -> (problem, tile row, tile column) for the DMA stream; `dq` follows the problem.  Returns true when the problem changed.
+  auto decode = [&](int id, int& pi, int& tm, int& tn) -> bool {
+    bool changed = false;
+    if (id < dq.tile_begin || id >= dq.tile_begin + dq.tiles_m * dq.tiles_n) {
+      int np = 0;
+      for (int j = 1; j < nprobs; ++j)
+        if (id >= args->p[j].tile_begin) np = j;
+      pi = np;
+      load_dq(np);
+      changed = true;
+    }
+    const int lt = id - dq.tile_begin;
+    const int gsz = GM * dq.tiles_n, group = lt / gsz, first_m = group * GM;
+    const int gm = dq.tiles_m - first_m < GM ? dq.tiles_m - first_m : GM;
     const int within = lt - group * gsz;
     tm = first_m + within % gm;
     tn = within / gm;
+    return changed;
   };
 
   // ---- DMA stream state: `pa`, `pb` point at the operand bytes of the stream's current K-tile ------------------------------------
-  int d_id = slot, d_pi, d_tm, d_tn, d_kt = 0, d_nkt;
+  int d_id = slot, d_pi = 0, d_tm, d_tn, d_kt = 0;
   const char *pa, *pb;
-  int64_t a_step, b_step;
+  uint32_t a_step, b_step;
   auto dma_set_tile = [&](bool new_ld) {
-    const int64_t lda = args->p[d_pi].lda, ldb = args->p[d_pi].ldb;
-    if (new_ld) set_offsets(lda, ldb);
-    pa = reinterpret_cast<const char*>(args->p[d_pi].A) + (A_KS ? (int64_t)d_tm * TM * 2 : (int64_t)d_tm * TM * lda * 2);
-    pb = reinterpret_cast<const char*>(args->p[d_pi].B) + (B_KS ? (int64_t)d_tn * TN * 2 : (int64_t)d_tn * TN * ldb * 2);
-    a_step = A_KS ? 128 * lda : 128;
-    b_step = B_KS ? 128 * ldb : 128;
-    d_nkt = args->p[d_pi].nkt;
+    if (new_ld) set_offsets(dq.lda, dq.ldb);
+    pa = dq.A + (A_KS ? (int64_t)d_tm * TM * 2 : (int64_t)d_tm * TM * dq.lda * 2);
+    pb = dq.B + (B_KS ? (int64_t)d_tn * TN * 2 : (int64_t)d_tn * TN * dq.ldb * 2);
+    a_step = A_KS ? 128u * dq.lda : 128u;
+    b_step = B_KS ? 128u * dq.ldb : 128u;
     d_kt = 0;
   };
   auto dma_advance = [&]() {   // to the next K-tile of the stream (the block's next tile after the last K-tile; wraps to its first tile)
     ++d_kt;
-    if (d_kt < d_nkt) {
+    if (d_kt < dq.nkt) {
       pa += a_step;
       pb += b_step;
     } else {
-      const int old_pi = d_pi;
       d_id += G;
       if (d_id >= ntiles) d_id = slot;
-      decode(d_id, d_pi, d_tm, d_tn);
-      dma_set_tile(d_pi != old_pi);
+      const bool changed = decode(d_id, d_pi, d_tm, d_tn);
+      dma_set_tile(changed);
     }
   };
-  // LDS-DMA through inline asm: with the builtin hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read_b64_tr_b16 that follows an
-  // LDS-DMA (it cannot tell the transposing read from the DMA's LDS store), which serialised every phase of the dX / dW kernels.
-  // The statement has no VGPR destination (register-safe); M0 = wave-uniform LDS byte address, saved and restored in the same
-  // statement (cdna_hip_programming 5.7); source = uniform 64-bit base in SGPRs + per-lane 32-bit byte offset.
+  // LDS-DMA through inline asm (header comment).  No VGPR destination (register-safe); M0 = wave-uniform LDS byte address, saved and
+  // restored in the same statement (cdna_hip_programming 5.7); source = uniform 64-bit base in SGPRs + per-lane 32-bit byte offset.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)smem;
+#ifndef MAFED_PP_ABL
+#define MAFED_PP_ABL 0   // tuning builds (timing only, wrong results): 1 no DMA in the K loop, 2 no fragment reads, 3 no MFMA, 4 = 1 + 2
+#endif
+  bool abl_dma_on = true;
   auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    if ((MAFED_PP_ABL == 1 || MAFED_PP_ABL == 4) && !abl_dma_on) return;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
   };
-  auto dma_a = [&](int stage, int i) { dma16(pa, aoff[i], lds0 + stage * STAGE + a_dst[i]); };
-  auto dma_b = [&](int stage, int i) { dma16(pb, boff[i], lds0 + stage * STAGE + b_dst[i]); };
-  // issue group g (stream order) of the stream's current K-tile into `stage`
-  auto dma_group = [&](int stage, int g) {
-    if constexpr (NPH == 4) {          // [B0 B1] [B2 B3] [A0 A1] [A2 A3]
-      if (g == 0) { dma_b(stage, 0); dma_b(stage, 1); }
-      else if (g == 1) { dma_b(stage, 2); dma_b(stage, 3); }
-      else if (g == 2) { dma_a(stage, 0); dma_a(stage, 1); }
-      else { dma_a(stage, 2); dma_a(stage, 3); }
-    } else {                           // [B0 B1 B2] [B3 A0] [A1 A2]
-      if (g == 0) { dma_b(stage, 0); dma_b(stage, 1); dma_b(stage, 2); }
-      else if (g == 1) { dma_b(stage, 3); dma_a(stage, 0); }
-      else { dma_a(stage, 1); dma_a(stage, 2); }
+  auto dma_a = [&](int so, int i) { dma16(pa + a_so[i], va, lds0 + so + a_dst[i]); };
+  auto dma_b = [&](int so, int i) { dma16(pb + b_so[i], vb[(PAIR && !B_KS) ? (i & 3) : (i & 1)], lds0 + so + b_dst[i]); };
+  // issue group g (stream order) of the stream's current K-tile into the stage at byte offset `so`
+  auto dma_group = [&](int so, int g) {
+    if constexpr (NPH == 3) {          // [B0 B1 B2] [B3 A0] [A1 A2]
+      if (g == 0) { dma_b(so, 0); dma_b(so, 1); dma_b(so, 2); }
+      else if (g == 1) { dma_b(so, 3); dma_a(so, 0); }
+      else { dma_a(so, 1); if (TM % 64 == 0 || wave < 2) dma_a(so, 2); }
+    } else {                           // [B0 B1 B2] [B3 A0 A1]
+      if (g == 0) { dma_b(so, 0); dma_b(so, 1); dma_b(so, 2); }
+      else { dma_b(so, 3); dma_a(so, 0); dma_a(so, 1); }
     }
   };
 
   f32x4 acc[NT][MT];
-  // fragments are read ONE PHASE AHEAD of the MFMA cluster that consumes them (a wave's own ds_read latency, ~300 cycles with eight
-  // waves reading, was exposed in front of every cluster otherwise): two sets of A fragments by phase parity, two of B by K-tile parity
-  // (NT = 4: one set of B fragments, 32 registers, re-read inside the last cluster of a K-tile as its two k-halves retire)
-  constexpr bool FB2 = NT == 2;
-  bf16x8 fb[FB2 ? 2 : 1][2][NT], fa[2][2][MTP];
+  // fragments are read ONE PHASE AHEAD of the MFMA cluster that consumes them: two sets of A fragments by phase parity, two of B by
+  // K-tile parity
+  bf16x8 fb[2][2][NT], fa[2][2][MTP];
+  if (MAFED_PP_ABL == 2 || MAFED_PP_ABL == 4) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[a][ks][nt] = __builtin_bit_cast(bf16x8, make_uint4(lane, a, ks, nt));
+#pragma unroll
+        for (int j = 0; j < MTP; ++j) fa[a][ks][j] = __builtin_bit_cast(bf16x8, make_uint4(lane, a, ks, j));
+      }
+  }
 #ifdef MAFED_PP_TRACE
   const bool trace_on = g_pp_trace != nullptr && blockIdx.x < 4;
   int trace_n = 0;
 #endif
 
-  auto read_b = [&](const char* st, bf16x8 (&dst)[2][NT], int ks0, int ks1) {
+  auto read_b = [&](const char* st, bf16x8 (&dst)[2][NT]) {
+    if (MAFED_PP_ABL == 2 || MAFED_PP_ABL == 4) {
 #pragma unroll
-    for (int ks = ks0; ks < ks1; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(dst[ks][nt]));
+      return;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if constexpr (!B_KS) {
@@ -256,6 +307,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
       }
   };
   auto read_a = [&](const char* st, int p, bf16x8 (&dst)[2][MTP]) {
+    if (MAFED_PP_ABL == 2 || MAFED_PP_ABL == 4) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < MTP; ++j) asm volatile("" : "+v"(dst[ks][j]));
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -277,14 +335,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   // the other fragment set; issue DMA; counted wait; MFMA cluster of phase J }: nothing in an interval waits for an LDS or a memory
   // round trip of its own.  A region (B, or the A rows of one phase) whose fragments are read in interval J-1 and consumed in
   // interval J is re-filled from interval J+1 on; data covered by a counted wait in interval j is read from interval j+1 on
-  // (tools/pp_schedule_check.py).  DMA issue groups per K-tile, in stream order:
-  //   NPH = 3: [B0 B1 B2] [B3 A0] [A1 A2]   slot 0: group 2 of K-tile kt+1 | slot 1: group 0 of kt+2, vmcnt(5) | slot 2: group 1 of kt+2, vmcnt(5)
-  //   NPH = 4: [B0 B1] [B2 B3] [A0 A1] [A2 A3]   slot 0: group 3 of kt+1, vmcnt(8) | slot 1: group 0 of kt+2 | slot 2: group 1, vmcnt(6) | slot 3: group 2
-  // `stage` = parity of the K-tile (compile-time after unrolling by two); `post` = first K-tile after an epilogue (its stores sit
-  // in the VMEM queue between the DMAs: the waits that still target a DMA issued before them count NST more operations).
-  // STAG: group 1 takes the barrier between its loads and its MFMA cluster (half a phase behind group 0; MI355X_MICROARCH "Two
-  // waves per SIMD" item 9); it then retires the PREVIOUS interval's fragment reads with a counted lgkmcnt before that barrier,
-  // which is where group 0 retires them (before its cluster).
+  // (tools/pp_schedule_check.py).  DMA issue groups per K-tile, in stream order, and the phase slot that issues them:
+  //   3 phases, 2 stages: [B0 B1 B2] [B3 A0] [A1 A2]   slot 0: group 2 of K-tile kt+1 | slot 1: group 0 of kt+2, vmcnt(5) | slot 2: group 1 of kt+2, vmcnt(5)
+  //     (a three-stage ring for this schedule, 5 - 6 phases of cover instead of 2 - 3, measured SLOWER, 824 vs 920 TFLOP/s on the
+  //      qkv product: the loop is bound by the L2 -> LDS rate of a CU, ~65 GB/s -- MI355X_MICROARCH "Indexed rows: gather into LDS"
+  //      gives 66-73 -- i.e. 632 of a phase's 752 cycles with the MFMAs removed, not by the latency of a piece)
+  //   2 phases, 3 stages: [B0 B1 B2] [B3 A0 A1]        slot 0: group 1 of K-tile kt+2, vmcnt(6) | slot 1: group 0 of kt+3
+  // `S` = parity of the K-tile (compile-time after unrolling by two: fragment sets; with two stages also the stage); `post` = 1 / 2 in
+  // the first / second K-tile after an epilogue (its stores sit in the VMEM queue between the DMAs: a wait that still targets a DMA
+  // issued before them counts NST more operations), else 0; `last` = last K-tile of the tile (the next tile reads its phase-0 fragments itself, after
+  // the epilogue: nothing stays live across it).
+  // Group 1 takes the barrier between its loads and its cluster (half a phase behind group 0; MI355X_MICROARCH "Two waves per SIMD"
+  // item 9) and retires the PREVIOUS interval's fragment reads with a counted lgkmcnt before it, where group 0 retires them (before
+  // its cluster).
+  int st0 = 0, st1 = STAGE, st2 = 2 * STAGE;   // three stages: byte offsets of the stages of K-tiles kt, kt+1, kt+2 (rotating)
+  (void)st2;
 #ifdef MAFED_PP_TRACE
   unsigned long long ts_cur = 0;
   int ts_tag = -1;
@@ -294,7 +359,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     PP_STAMP(ts_cur);
     ts_tag = tag;
     if (trace_on && (wave & 3) == 0 && lane == 0 && prev_tag >= 0 && trace_n < PP_TRACE_REC) {
-      unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE + 2048) + (grp * PP_TRACE_REC + trace_n) * 2;
+      unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + NSTG * STAGE + 2048) + (grp * PP_TRACE_REC + trace_n) * 2;
       tr[0] = prev; tr[1] = (unsigned long long)prev_tag;
     }
     if (prev_tag >= 0) ++trace_n;
@@ -305,69 +370,62 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
 #ifndef MAFED_PP_STAGGER
 #define MAFED_PP_STAGGER 1
 #endif
-  constexpr bool STAG = MAFED_PP_STAGGER != 0 && FB2;   // (the in-cluster B refresh of NT = 4 reads B after the barrier a staggered group 1 would take: uniform program there)
+  constexpr bool STAG = MAFED_PP_STAGGER != 0;
   constexpr int RD_A = (A_KS ? 4 : 2) * MTP, RD_B = (B_KS ? 4 : 2) * NT;   // LDS read instructions of one phase's A / one K-tile's B fragments
-  auto seg_load = [&](auto stage_c, int p, int set, bool post) {
+  auto seg_load = [&](auto stage_c, int p, int set, int post, bool last) {
     constexpr int S = decltype(stage_c)::value;
+    const int so_c = NSTG == 2 ? S * STAGE : st0, so_n = NSTG == 2 ? (S ^ 1) * STAGE : st1;
     if (p + 1 < NPH) {
-      read_a(smem + S * STAGE, p + 1, fa[set ^ 1]);
-    } else {
-      if constexpr (FB2) read_b(smem + (S ^ 1) * STAGE, fb[S ^ 1], 0, 2);
-      read_a(smem + (S ^ 1) * STAGE, 0, fa[set ^ 1]);
+      read_a(smem + so_c, p + 1, fa[set ^ 1]);
+    } else if (!last) {
+      read_b(smem + so_n, fb[S ^ 1]);
+      read_a(smem + so_n, 0, fa[set ^ 1]);
     }
-    if constexpr (NPH == 4) {
-      if (p == 0) dma_group(S ^ 1, 3);
-      if (p == 1) { dma_advance(); dma_group(S, 0); }
-      if (p == 2) dma_group(S, 1);
-      if (p == 3) dma_group(S, 2);
-    } else {
-      if (p == 0) dma_group(S ^ 1, 2);
-      if (p == 1) { dma_advance(); dma_group(S, 0); }
-      if (p == 2) dma_group(S, 1);
-    }
-    if constexpr (NPH == 4) {
-      if (p == 0) { if (post) pp_wait_vmcnt<(8 + NST > 63 ? 63 : 8 + NST)>(); else pp_wait_vmcnt<8>(); }
-      if (p == 2) { if (post) pp_wait_vmcnt<(6 + NST > 63 ? 63 : 6 + NST)>(); else pp_wait_vmcnt<6>(); }
-    } else {
-      if (p == 1) { if (post) pp_wait_vmcnt<(5 + NST > 63 ? 63 : 5 + NST)>(); else pp_wait_vmcnt<5>(); }
+    if constexpr (NPH == 3 && NSTG == 2) {
+      if (p == 0) dma_group(so_n, 2);
+      if (p == 1) { dma_advance(); dma_group(so_c, 0); }
+      if (p == 2) dma_group(so_c, 1);
+      // (the wait of slot 1 leaves group 2 of K-tile kt+1 and group 0 of kt+2 in flight: 2 + 3 pieces, 1 + 3 for the waves whose
+      //  group 2 is a single piece)
+      if (p == 1) {
+        if (TM % 64 == 0 || wave < 2) { if (post == 1) pp_wait_vmcnt<(5 + NST > 63 ? 63 : 5 + NST)>(); else pp_wait_vmcnt<5>(); }
+        else { if (post == 1) pp_wait_vmcnt<(4 + NST > 63 ? 63 : 4 + NST)>(); else pp_wait_vmcnt<4>(); }
+      }
       if (p == 2) pp_wait_vmcnt<5>();
+    } else {
+      if (p == 0) dma_group(st2, 1);
+      if (p == 1) { dma_advance(); dma_group(st0, 0); }
+      if (p == 0) { if (post == 1) pp_wait_vmcnt<(6 + NST > 63 ? 63 : 6 + NST)>(); else pp_wait_vmcnt<6>(); }
     }
   };
   auto seg_mfma = [&](int S, int p, int set) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < MTP; ++j)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt][p * MTP + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[FB2 ? S : 0][ks][nt], fa[set][ks][j], acc[nt][p * MTP + j], 0, 0, 0);
-      if constexpr (!FB2) {
-        // last cluster of the K-tile: this k-half of the B fragments is dead, fetch the next K-tile's into the same registers
-        if (p == NPH - 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          read_b(smem + (S ^ 1) * STAGE, fb[0], ks, ks + 1);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < NT; ++nt) {
+          if (MAFED_PP_ABL == 3) { asm volatile("" ::"v"(fb[S][ks][nt]), "v"(fa[set][ks][j])); continue; }
+          acc[nt][p * MTP + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[S][ks][nt], fa[set][ks][j], acc[nt][p * MTP + j], 0, 0, 0);
         }
-      }
-    }
     __builtin_amdgcn_s_setprio(0);
   };
   // (one lambda instance per group: a wave-uniform branch INSIDE the phase loop makes the register allocator join all accumulators
   //  at every phase and spill; the two groups' loops meet only at the epilogue)
-  auto ktile = [&](auto stage_c, auto grp_c, bool post) {
+  auto ktile = [&](auto stage_c, auto grp_c, int post, bool last) {
     constexpr int S = decltype(stage_c)::value, GRP = decltype(grp_c)::value;
 #pragma unroll
     for (int p = 0; p < NPH; ++p) {
       const int set = (S * NPH + p) & 1;
       __builtin_amdgcn_sched_barrier(0);
       trace_event(0);
-      seg_load(stage_c, p, set, post);
+      seg_load(stage_c, p, set, post, last);
       if constexpr (STAG && GRP == 1) {
         // the reads of the previous interval (consumed by the cluster below, after the barrier) retire here: only this interval's remain
-        constexpr int NEW_B = RD_B, NEW_A = RD_A;
-        if (p + 1 < NPH) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NEW_A > 15 ? 15 : NEW_A) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NEW_A + NEW_B > 15 ? 15 : NEW_A + NEW_B) : "memory");
+        if (p + 1 < NPH) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A > 15 ? 15 : RD_A) : "memory");
+        else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD_A + RD_B > 15 ? 15 : RD_A + RD_B) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
       }
@@ -376,6 +434,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(STAG && GRP == 1)) __builtin_amdgcn_s_barrier();
     }
+    if constexpr (NSTG == 3) { const int t = st0; st0 = st1; st1 = st2; st2 = t; }
   };
 
   // ---- epilogue: straight from the accumulators, 64-byte row segments per store instruction -------------------------------------
@@ -388,19 +447,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   constexpr int GSTEP = PAIR ? 32 : 16;
   auto epilogue_fast = [&](auto mode_c, auto hsrc_c, auto fsrc_c, int pi, int tm, int tn) {
     constexpr int MODE = decltype(mode_c)::value, HSRC = decltype(hsrc_c)::value, FSRC = decltype(fsrc_c)::value;
-    CT* __restrict__ C = reinterpret_cast<CT*>(args->p[pi].C);
-    const float* __restrict__ bias = args->p[pi].bias;
-    CT* aux = reinterpret_cast<CT*>(args->p[pi].aux);
-    const bf16_t* res1 = reinterpret_cast<const bf16_t*>(args->p[pi].res1);
-    const float* res2 = args->p[pi].res2;
-    float* colsum = args->p[pi].colsum;
-    const int64_t ldc = args->p[pi].ldc;
-    const float beta = args->p[pi].beta;
-    const int64_t row0 = (int64_t)tm * TM + wm * MT * 16 + li;
-    const int64_t col0 = (int64_t)tn * TN + wn * NT * 16 + (PAIR ? 8 * q4 : 4 * q4);
+    CT* __restrict__ C = reinterpret_cast<CT*>(cq.C);
+    const float* __restrict__ bias = cq.bias;
+    CT* aux = reinterpret_cast<CT*>(cq.aux);
+    const bf16_t* res1 = reinterpret_cast<const bf16_t*>(cq.res1);
+    const float* res2 = cq.res2;
+    float* colsum = cq.colsum;
+    const int64_t ldc = cq.ldc;
+    const float beta = cq.beta;
+    const int64_t row0 = (int64_t)tm * TM + li;
+    const int64_t col0 = (int64_t)tn * TN + wave * NT * 16 + (PAIR ? 8 * q4 : 4 * q4);
     struct Pre { uint4 h; float4 f0, f1; };
     constexpr int PD = 3;
-    float* scr = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 64;
+    float* scr = reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int64_t cg = col0 + g * GSTEP;
@@ -505,19 +564,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     if (colsum) {
       // one atomic instruction of contiguous floats per wave and tile (full-rate shape of MI355X_MICROARCH "Global float atomics")
       __builtin_amdgcn_wave_barrier();
-      if (lane < NT * 16) atomicAdd(colsum + (int64_t)tn * TN + wn * NT * 16 + lane, scr[lane]);
+      if (lane < NT * 16) atomicAdd(colsum + (int64_t)tn * TN + wave * NT * 16 + lane, scr[lane]);
       __builtin_amdgcn_wave_barrier();
     }
   };
   // any other epilogue combination: the in-place operand loads of gemm_epilogue.h (no prefetch, no fused column sums)
   auto epilogue_generic = [&](int pi, int tm, int tn) {
     GemmEpi e;
-    e.bias = args->p[pi].bias; e.mode = args->p[pi].mode; e.aux = args->p[pi].aux;
-    e.res1 = reinterpret_cast<const float*>(args->p[pi].res1); e.res2 = args->p[pi].res2; e.res1_bf16 = args->p[pi].res1_bf16;
-    e.beta = args->p[pi].beta; e.ldc = args->p[pi].ldc; e.colsum = nullptr;
-    CT* C = reinterpret_cast<CT*>(args->p[pi].C);
-    const int64_t row0 = (int64_t)tm * TM + wm * MT * 16 + li;
-    const int64_t col0 = (int64_t)tn * TN + wn * NT * 16 + (PAIR ? 8 * q4 : 4 * q4);
+    e.bias = cq.bias; e.mode = cq.mode; e.aux = cq.aux;
+    e.res1 = reinterpret_cast<const float*>(cq.res1); e.res2 = cq.res2; e.res1_bf16 = cq.res1_bf16;
+    e.beta = cq.beta; e.ldc = cq.ldc; e.colsum = nullptr;
+    CT* C = reinterpret_cast<CT*>(cq.C);
+    const int64_t row0 = (int64_t)tm * TM + li;
+    const int64_t col0 = (int64_t)tn * TN + wave * NT * 16 + (PAIR ? 8 * q4 : 4 * q4);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -534,9 +593,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   };
   auto epilogue = [&](int pi, int tm, int tn) {
     using std::integral_constant;
-    const int mode = args->p[pi].mode;
-    const bool r1 = args->p[pi].res1 != nullptr, r1h = r1 && args->p[pi].res1_bf16, r2 = args->p[pi].res2 != nullptr;
-    const bool bt = args->p[pi].beta != 0.f;
+    const int mode = cq.mode;
+    const bool r1 = cq.res1 != nullptr, r1h = r1 && cq.res1_bf16, r2 = cq.res2 != nullptr;
+    const bool bt = cq.beta != 0.f;
     if (mode == MAFED_EPI_NONE && !r1 && !r2 && !bt)
       epilogue_fast(integral_constant<int, MAFED_EPI_NONE>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, pi, tm, tn);
     else if (mode == MAFED_EPI_GELU && !r1 && !r2 && !bt)
@@ -553,38 +612,47 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
 
   // ---- main ----------------------------------------------------------------------------------------------------------------
   if (slot >= ntiles) return;
-  int id = slot, pi, tm, tn;
-  decode(id, pi, tm, tn);
-  d_pi = pi; d_tm = tm; d_tn = tn;
+  int id = slot, pi = 0, tm, tn;
+  load_dq(0);
+  decode(id, d_pi, d_tm, d_tn);
+  pi = d_pi; tm = d_tm; tn = d_tn;
+  load_cq(pi);
   dma_set_tile(true);
-  // prologue = "interval -1": K-tile 0 (all groups) into stage 0 and the first NPH - 1 groups of K-tile 1 into stage 1, as the steady
-  // state would have by now; every piece of K-tile 0 that phases 0 and 1 read has landed once only those of K-tile 1 (and, NPH = 4,
-  // K-tile 0's last group) remain; then phase 0's fragments
-#pragma unroll
-  for (int g = 0; g < NPH; ++g) dma_group(0, g);
-  dma_advance();
-#pragma unroll
-  for (int g = 0; g < NPH - 1; ++g) dma_group(1, g);
-  if constexpr (NPH == 4) pp_wait_vmcnt<8>(); else pp_wait_vmcnt<5>();
+  // prologue = "interval -1": what the steady state would have issued by now, then a wait that covers every piece of K-tile 0
+  if constexpr (NPH == 3 && NSTG == 2) {
+    dma_group(0, 0); dma_group(0, 1); dma_group(0, 2);
+    dma_advance();
+    dma_group(STAGE, 0); dma_group(STAGE, 1);
+    pp_wait_vmcnt<5>();
+  } else {
+    dma_group(0, 0); dma_group(0, 1);
+    dma_advance();
+    dma_group(STAGE, 0); dma_group(STAGE, 1);
+    dma_advance();
+    dma_group(2 * STAGE, 0);
+    pp_wait_vmcnt<9>();
+  }
   __builtin_amdgcn_s_barrier();
-  read_b(smem, fb[0], 0, 2);
-  read_a(smem, 0, fa[0]);
+  abl_dma_on = false;
   bool first = true;
   while (true) {
-    const int nkt = args->p[pi].nkt;
+    const int nkt = cq.nkt;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // phase 0's fragments (K-tile 0 of this tile landed and was published before the previous tile's last barrier / the prologue's)
+    read_b(smem + (NSTG == 2 ? 0 : st0), fb[0]);
+    read_a(smem + (NSTG == 2 ? 0 : st0), 0, fa[0]);
     if (grp == 0) {
       for (int kt = 0; kt < nkt; kt += 2) {
-        ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, !first && kt == 0);
-        ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, false);
+        ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, (!first && kt == 0) ? 1 : 0, false);
+        ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, (!first && kt == 0) ? 2 : 0, kt + 2 >= nkt);
       }
     } else {
       for (int kt = 0; kt < nkt; kt += 2) {
-        ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, !first && kt == 0);
-        ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, false);
+        ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, (!first && kt == 0) ? 1 : 0, false);
+        ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, (!first && kt == 0) ? 2 : 0, kt + 2 >= nkt);
       }
     }
     trace_event(1);
@@ -593,13 +661,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     first = false;
     id += G;
     if (id >= ntiles) break;
-    decode(id, pi, tm, tn);
+    // the DMA stream switched to this tile K-tiles ago: its coordinates are already decoded
+    if (d_pi != pi) load_cq(d_pi);
+    pi = d_pi; tm = d_tm; tn = d_tn;
     trace_event(3);
   }
   trace_event(3);
 #ifdef MAFED_PP_TRACE
   if (trace_on && (wave & 3) == 0 && lane == 0) {
-    const unsigned long long* tr = reinterpret_cast<const unsigned long long*>(smem + 2 * STAGE + 2048) + grp * PP_TRACE_REC * 2;
+    const unsigned long long* tr = reinterpret_cast<const unsigned long long*>(smem + NSTG * STAGE + 2048) + grp * PP_TRACE_REC * 2;
     unsigned long long* dst = g_pp_trace + ((int64_t)blockIdx.x * 2 + grp) * (PP_TRACE_REC * 2 + 1);
     const int n = trace_n < PP_TRACE_REC ? trace_n : PP_TRACE_REC;
     dst[0] = n;
@@ -611,11 +681,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MT, int NT, bool A_KS, bool B_KS, typename CT>
+template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
 static int pp_launch_t(const PPArgs& a, double flops, hipStream_t st) {
-  constexpr int TM = WM * MT * 16, TN = WN * NT * 16;
-  constexpr int LDS = 2 * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES;
-  auto kfn = gemm_pp_kernel<WM, WN, MT, NT, A_KS, B_KS, CT>;
+  constexpr int TM = MT * 16, TN = 8 * NT * 16;
+  constexpr int LDS = NSTG * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES;
+  auto kfn = gemm_pp_kernel<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -628,15 +698,16 @@ static int pp_launch_t(const PPArgs& a, double flops, hipStream_t st) {
 
 static void pp_tile_shape(int cfg, int& TM, int& TN) {
   TN = 256;
-  TM = cfg == PP_256x256 ? 256 : (cfg == PP_192x256 ? 192 : 144);
+  TM = cfg == PP_128x256 ? 128 : 144;
 }
 
-int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N, int64_t K, int force_cfg) {
+int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int force_cfg) {
   if (K % 128 != 0 || K < 256 || N % 256 != 0) return PP_NONE;
+  if (lda % 64 != 0 || ldb % 64 != 0 || lda >= (1 << 22) || ldb >= (1 << 22)) return PP_NONE;   // 32-bit piece offsets
   auto inst = [&](int cfg) {   // instantiated (layout, output type, configuration) combinations
-    if (a_ks && b_ks) return cfg == PP_256x256 && c_dtype == MAFED_F32;
+    if (a_ks && b_ks) return cfg == PP_128x256 && c_dtype == MAFED_F32;
     if (a_ks) return false;
-    if (cfg == PP_256x256) return false;
+    if (cfg != PP_144x256) return false;
     if (b_ks) return c_dtype == MAFED_BF16;
     return true;
   };
@@ -646,20 +717,9 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N
     return inst(cfg) && M % TM == 0 && N % TN == 0;
   };
   if (force_cfg >= 0) return fits(force_cfg) ? force_cfg : PP_NONE;
-  int best = PP_NONE;
-  double best_cost = 1e30;
-  for (int cfg = 0; cfg < 3; ++cfg) {
-    if (!fits(cfg)) continue;
-    int TM, TN;
-    pp_tile_shape(cfg, TM, TN);
-    const int64_t tiles = (M / TM) * (N / TN);
-    const int64_t rounds = (tiles + 255) / 256;
-    // time ~ rounds x tile area, with the measured relative loop efficiency of the wave tile (144x32 reads more LDS per MFMA)
-    const double eff = cfg == PP_144x256 ? 0.88 : 1.0;
-    const double cost = (double)rounds * TM * TN / eff;
-    if (cost < best_cost) { best_cost = cost; best = cfg; }
-  }
-  return best;
+  for (int cfg = 0; cfg < PP_NCFG; ++cfg)
+    if (fits(cfg)) return cfg;
+  return PP_NONE;
 }
 
 int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,
@@ -687,18 +747,15 @@ int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPP
   a.ntiles = tiles;
   // the 32 CUs of an XCD take 32 consecutive tile ids: GROUP_M row tiles x (32 / GROUP_M) column tiles form a compact patch
   a.group_m = min_tn >= 8 ? 4 : (min_tn >= 4 ? 8 : 16);
-#define PP_GO(WM, WN, MT, NT, AKS, BKS, CT) return pp_launch_t<WM, WN, MT, NT, AKS, BKS, CT>(a, flops, st)
+#define PP_GO(MT, NT, NPH, NSTG, AKS, BKS, CT) return pp_launch_t<MT, NT, NPH, NSTG, AKS, BKS, CT>(a, flops, st)
   const bool f32 = c_dtype == MAFED_F32;
   if (a_ks && b_ks) {
-    if (cfg == PP_256x256 && f32) PP_GO(2, 4, 8, 4, true, true, float);
+    if (cfg == PP_128x256 && f32) PP_GO(8, 2, 2, 3, true, true, float);
   } else if (!a_ks && b_ks) {
-    if (cfg == PP_192x256 && !f32) PP_GO(2, 4, 6, 4, false, true, bf16_t);
-    if (cfg == PP_144x256 && !f32) PP_GO(1, 8, 9, 2, false, true, bf16_t);
+    if (cfg == PP_144x256 && !f32) PP_GO(9, 2, 3, 2, false, true, bf16_t);
   } else if (!a_ks && !b_ks) {
-    if (cfg == PP_192x256 && !f32) PP_GO(2, 4, 6, 4, false, false, bf16_t);
-    if (cfg == PP_192x256 && f32) PP_GO(2, 4, 6, 4, false, false, float);
-    if (cfg == PP_144x256 && !f32) PP_GO(1, 8, 9, 2, false, false, bf16_t);
-    if (cfg == PP_144x256 && f32) PP_GO(1, 8, 9, 2, false, false, float);
+    if (cfg == PP_144x256 && !f32) PP_GO(9, 2, 3, 2, false, false, bf16_t);
+    if (cfg == PP_144x256 && f32) PP_GO(9, 2, 3, 2, false, false, float);
   }
 #undef PP_GO
   set_error("gemm_pp: configuration %d not instantiated for this layout / output type", cfg);

@@ -194,6 +194,10 @@ class VLPythiaForCausalLM(nn.Module):
         self._side = None
         self._view_cache: Dict[Tuple[int, str], torch.Tensor] = {}
         self.overlap_param_grads = True  # run dW / bias-gradient kernels on side_stream() concurrently with the dX chain
+        # bf16: the four weight gradients dW += dY^T.X of `dw_group_layers` consecutive layers are deferred and launched as ONE grouped
+        # persistent GEMM (mafed_gemm_grouped) on the main stream: 2 layers = 768 tiles of 128 x 256 = three whole rounds of the
+        # 256 CUs without split-K (one layer's products alone leave a third to seven eighths of the chip idle); 0 = one launch each
+        self.dw_group_layers = 2
         self.sparse_lm_head = True          # batches that carry ``max_label_rows`` get the row-sparse LM head in training
         self.defer_ln_param_reduce = True   # LayerNorm parameter-gradient reduction on a side stream (needs overlap_param_grads)
         self.reset_parameters(seed)
@@ -711,6 +715,28 @@ class VLPythiaForCausalLM(nn.Module):
                     ops.colsum_(dY, g(bname))
             on_side(run, dY, X)
 
+        # layer weight gradients, grouped: (dY, X, gradient) records wait here (the list keeps dY / X alive) until `flush_dw`
+        group_dw = cd == torch.bfloat16 and int(getattr(self, "dw_group_layers", 0)) > 0
+        pending_dw: List[dict] = []
+        pending_layers: List[int] = []
+
+        def wgrad_layer(dY, X, wname, bname=None):
+            if not group_dw:
+                wgrad(dY, X, wname, bname)
+                return
+            pending_dw.append(dict(A=dY, B=X, out=g(wname), beta=1.0))
+            if bname is not None:
+                on_side(lambda: ops.colsum_(dY, g(bname)), dY)
+
+        def flush_dw():
+            if pending_dw:
+                ops.gemm_grouped(pending_dw, True, False)
+                pending_dw.clear()
+                main_moved()
+            for li in pending_layers:
+                ready(li)
+            pending_layers.clear()
+
         def ready(i):
             """Bucket hook: fires on side stream 0 once every side stream has finished the gradients queued so far."""
             if self.grad_ready_hook is None:
@@ -786,21 +812,21 @@ class VLPythiaForCausalLM(nn.Module):
             pre = f"gpt_neox.layers.{i}."
             s = sv["layers"][i]
             # parameter gradients that only need dy: MLP down-projection and attention output projection
-            wgrad(dy, s["a"], pre + "mlp.dense_4h_to_h.weight", None if dy_bias_done else pre + "mlp.dense_4h_to_h.bias")
-            wgrad(dy, s["ao"], pre + "attention.dense.weight", None if dy_bias_done else pre + "attention.dense.bias")
+            wgrad_layer(dy, s["a"], pre + "mlp.dense_4h_to_h.weight", None if dy_bias_done else pre + "mlp.dense_4h_to_h.bias")
+            wgrad_layer(dy, s["ao"], pre + "attention.dense.weight", None if dy_bias_done else pre + "attention.dense.bias")
             # MLP branch
             # (the bias gradients of the two up-projections are column sums of du / dqkv: folded into the producing kernels)
             du = ops.gemm(dy, w(pre + "mlp.dense_4h_to_h.weight"), False, False, epilogue=EPI_GELU_BWD, aux=s["u"],
                           colsum=g(pre + "mlp.dense_h_to_4h.bias"))
             main_moved()
-            wgrad(du, s["ln2"], pre + "mlp.dense_h_to_4h.weight")
+            wgrad_layer(du, s["ln2"], pre + "mlp.dense_h_to_4h.weight")
             dln2 = ops.gemm(du, w(pre + "mlp.dense_h_to_4h.weight"), False, False)
             # attention branch
             dao = ops.gemm(dy, w(pre + "attention.dense.weight"), False, False)
             dqkv = ops.attn_bwd(s["qkv"], s["ao"], dao, s["lse"], B, S, H, D, rot, cos, sin, am,
                                 colsum=g(pre + "attention.query_key_value.bias"))
             main_moved()
-            wgrad(dqkv, s["ln1"], pre + "attention.query_key_value.weight")
+            wgrad_layer(dqkv, s["ln1"], pre + "attention.query_key_value.weight")
             dln1 = ops.gemm(dqkv, w(pre + "attention.query_key_value.weight"), False, False)
             # both LayerNorms + the residual path, one pass; also emits the compute-dtype copy the next layer's GEMMs read
             ln_kw = dict(want_lp=(cd != torch.float32), teacher=inj[0].view(rows, h) if inj is not None else None,
@@ -828,7 +854,13 @@ class VLPythiaForCausalLM(nn.Module):
                 dy = dx
             if taps is not None and i in taps:
                 taps[i] = dx  # = dL/d hidden_states[i] (fresh buffer, never written again on this path)
-            ready(i)
+            if group_dw:
+                pending_layers.append(i)
+                if len(pending_layers) >= int(self.dw_group_layers):
+                    flush_dw()
+            else:
+                ready(i)
+        flush_dw()
         # every layer's LayerNorm / distillation kernel -- the last readers of the teacher's hidden states -- is queued: a consumer
         # that only has to stay behind THOSE (the next step's teacher forward re-uses that memory) can wait for this event instead of
         # for the whole backward, whose side streams still carry ~0.3 ms of parameter-gradient tail

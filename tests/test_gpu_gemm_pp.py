@@ -48,13 +48,13 @@ class forced:
 
 
 # (cfg, tA, tB, out dtype): the instantiated combinations (gemm_pp_launch)
-COMBOS = [(1, False, True, BF), (1, False, True, F32), (2, False, True, BF), (2, False, True, F32),
-          (1, False, False, BF), (2, False, False, BF), (0, True, False, F32)]
-TM = {0: 256, 1: 192, 2: 144}
+# configuration 0 = 144 x 256 tiles (forward / dX), 1 = 128 x 256 tiles (dW: both operands reduction-major)
+COMBOS = [(0, False, True, BF), (0, False, True, F32), (0, False, False, BF), (1, True, False, F32)]
+TM = {0: 144, 1: 128}
 
 
 @pytest.mark.parametrize("cfg,tA,tB,od", COMBOS)
-@pytest.mark.parametrize("tiles_m,tiles_n,K", [(1, 1, 256), (3, 2, 384), (2, 1, 1024), (5, 3, 256)])
+@pytest.mark.parametrize("tiles_m,tiles_n,K", [(1, 1, 256), (3, 2, 384), (2, 1, 1024), (5, 3, 256), (2, 2, 640)])
 def test_pp_exact_integers(cfg, tA, tB, od, tiles_m, tiles_n, K):
     """Small-integer operands are exact in bf16, in the fp32 accumulator and (|sum| <= 256 at K = 256; checked in fp32 otherwise) in
     the output: a wrong DMA permutation, swizzle, fragment or column map is a hard mismatch."""
@@ -112,7 +112,7 @@ def test_pp_grouped_launch(cfg, tA, tB, od):
         assert float((q["out"].double().cpu() - r).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("cfg", [0])
 def test_pp_epilogues_forward(cfg):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
@@ -151,7 +151,7 @@ def test_pp_epilogues_forward(cfg):
     assert float((cg.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("cfg", [0])
 def test_pp_gelu_backward_with_column_sums(cfg):
     """dX = dY.W with the GELU' epilogue and the fused bias gradient (column sums of the stored C)."""
     ops = _ops()
@@ -176,14 +176,14 @@ def test_pp_gelu_backward_with_column_sums(cfg):
 
 
 def test_pp_weight_gradient_accumulates():
-    """dW += dY^T.X (both operands [k][row]) through the 256x256 configuration, twice into the same buffer."""
+    """dW += dY^T.X (both operands [k][row]) through the 128x256 configuration, twice into the same buffer."""
     ops = _ops()
     g = torch.Generator().manual_seed(6)
     Kd, M, N = 1152, 512, 768
     dY, X = torch.randn(Kd, M, generator=g), torch.randn(Kd, N, generator=g)
     dYd, Xd = dY.to(DEV, BF), X.to(DEV, BF)
     G = torch.zeros(M, N, device=DEV)
-    with forced(0, 2):
+    with forced(1, 2):
         ops.gemm(dYd, Xd, True, False, out=G, beta=1.0)
         ops.gemm(dYd, Xd, True, False, out=G, beta=1.0)
     want = 2 * (dYd.float().cpu().double().t() @ Xd.float().cpu().double())

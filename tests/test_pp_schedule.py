@@ -27,12 +27,12 @@ def test_bank_conflicts(c):
 
 
 @pytest.mark.parametrize("c", CFGS, ids=IDS)
-@pytest.mark.parametrize("nst,extra", [(9, 0), (12, 12), (18, 18), (32, 0), (24, 40)])
+@pytest.mark.parametrize("nst,extra", [(9, 0), (9, 9), (16, 20), (18, 18), (18, 40)])
 def test_dma_schedule_has_no_raw_or_war_hazard(c, nst, extra):
     assert P.check_schedule(c, nst=nst, extra_epilogue_ops=extra) == []
 
 
 def test_checker_detects_a_loosened_wait(monkeypatch):
-    c = P.Cfg("192x256", False, False, True)
-    monkeypatch.setattr(P, "waits_of", lambda c, post, nst: {1: 6, 2: 5})
+    c = P.Cfg("144x256", False, False, True)
+    monkeypatch.setattr(P, "waits_of", lambda c, wave, post, nst: {1: 6, 2: 5})
     assert P.check_schedule(c) != []
