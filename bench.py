@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--no-defer-ln", action="store_true", help="LayerNorm parameter reduction on the dX stream (A/B)")
     ap.add_argument("--no-incremental-norm", action="store_true", help="clip norm in one pass at the start of the optimiser step (A/B)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
+    ap.add_argument("--no-overlap-teacher", action="store_true", help="teacher forward on the caller's stream (A/B)")
+    ap.add_argument("--no-overlap-dw", action="store_true", help="parameter-gradient work on the caller's stream (A/B)")
+    ap.add_argument("--dw-group-layers", type=int, default=None, help="layers per grouped weight-gradient launch (0 = one launch per product)")
     ap.add_argument("--reduce-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the links")
@@ -205,6 +208,12 @@ def main():
     if args.no_overlap:
         student.overlap_param_grads = False
         fd.overlap_teacher = False
+    if args.no_overlap_teacher:
+        fd.overlap_teacher = False
+    if args.no_overlap_dw:
+        student.overlap_param_grads = False
+    if args.dw_group_layers is not None:
+        student.dw_group_layers = args.dw_group_layers
     n_mem = 8 * B
     gcpu = torch.Generator().manual_seed(1235 + rank)
     ids = torch.randint(1, cfg.vocab_size, (n_mem, T), generator=gcpu)

@@ -23,7 +23,11 @@
 //     (bf16 C: a lane owns 8 consecutive columns of a row over its two fragments), no LDS round trip in the epilogue.
 //   * tile shapes: 144 x 256 (wave tile 144 x 32, three phases, two stages: every M = 9216 product of the step is a whole number
 //     of rounds of 256 CUs -- N = 1024 / 3072 / 4096 -> 256 / 768 / 1024 tiles) and 128 x 256 (wave tile 128 x 32, two phases,
-//     three stages: the weight gradients, whose operands are both reduction-major).
+//     three stages: the weight gradients, whose operands are both reduction-major).  The loop is bound by a CU's L2 -> LDS rate
+//     (~65 GB/s measured; 632 of a phase's 752 cycles with the MFMAs removed), so a larger tile -- fewer operand bytes per MFMA --
+//     is the next step; 192 x 256 and 256 x 256 wave-tile variants of this structure (12 / 16 row fragments, 96 / 128 accumulator
+//     registers + double-buffered fragments) were built and spilled 28 - 217 registers: a spilled register anywhere puts a
+//     vmcnt(0) for its scratch reload into the loop, so they are not instantiated.
 //   * grouped launches: up to 16 problems (same layouts / output type) share one grid; the tile space is their concatenation.
 //   * problem fields live in SGPRs and are re-read from the kernarg table only when the problem changes (a scalar load is a ~1 us
 //     round trip; a chain of them in front of every tile cost a K = 1024 tile a quarter of its time).
@@ -280,16 +284,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   int trace_n = 0;
 #endif
 
-  auto read_b = [&](const char* st, bf16x8 (&dst)[2][NT]) {
+  auto read_b = [&](const char* st, bf16x8 (&dst)[2][NT], int ks0 = 0, int ks1 = 2) {
     if (MAFED_PP_ABL == 2 || MAFED_PP_ABL == 4) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = ks0; ks < ks1; ++ks)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(dst[ks][nt]));
       return;
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = ks0; ks < ks1; ++ks)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if constexpr (!B_KS) {
@@ -707,7 +711,7 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N
   auto inst = [&](int cfg) {   // instantiated (layout, output type, configuration) combinations
     if (a_ks && b_ks) return cfg == PP_128x256 && c_dtype == MAFED_F32;
     if (a_ks) return false;
-    if (cfg != PP_144x256) return false;
+    if (cfg == PP_128x256) return false;
     if (b_ks) return c_dtype == MAFED_BF16;
     return true;
   };
@@ -717,9 +721,18 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N
     return inst(cfg) && M % TM == 0 && N % TN == 0;
   };
   if (force_cfg >= 0) return fits(force_cfg) ? force_cfg : PP_NONE;
-  for (int cfg = 0; cfg < PP_NCFG; ++cfg)
-    if (fits(cfg)) return cfg;
-  return PP_NONE;
+  // whole rounds of the 256 CUs first, then the larger tile (fewer operand bytes per MFMA through the L2 -> LDS path, which bounds the loop)
+  int best = PP_NONE;
+  double best_score = -1.0;
+  for (int cfg = 0; cfg < PP_NCFG; ++cfg) {
+    if (!fits(cfg)) continue;
+    int TM, TN;
+    pp_tile_shape(cfg, TM, TN);
+    const int64_t tiles = (M / TM) * (N / TN), rounds = (tiles + 255) / 256;
+    const double score = (double)tiles / (double)(rounds * 256);
+    if (score > best_score) { best_score = score; best = cfg; }
+  }
+  return best;
 }
 
 int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,

@@ -378,7 +378,7 @@ def all_cfgs():
     out = []
     for name in CONFIGS:
         for a_ks, b_ks, pair in itertools.product((False, True), (False, True), (False, True)):
-            if a_ks and not name.startswith("128x256"):
+            if a_ks and CONFIGS[name][0] // CONFIGS[name][2] != 4:
                 continue     # the regional [k][64] A image needs four fragments per phase region
             out.append(Cfg(name, a_ks, b_ks, pair))
     return out
