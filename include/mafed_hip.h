@@ -307,7 +307,7 @@ const char* mafed_prof_tag_name(int tag);
  * 100 + n = force n K-splits where legal */
 int mafed_gemm_set_variant(int variant);
 /* 700 = never take the persistent ping-pong kernel, 701 = automatic (default), 710 + c = force its tile configuration c
- * (0: 144x256 tiles, 1: 128x256 tiles) wherever the shape tiles it.  mafed_gemm_pp_launches(): launches that took that kernel so far
+ * (0: 144x256 tiles, 1: 128x256 tiles, 2: 256x256 tiles) wherever the shape tiles it.  mafed_gemm_pp_launches(): launches that took that kernel so far
  * (tests assert that a forced configuration really ran). */
 int mafed_gemm_pp_launches(void);
 

@@ -701,7 +701,7 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
   bool one = in_dtype == MAFED_BF16 && n <= PP_MAXP && ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0);
   const bool a_ks = transA != 0, b_ks = transB == 0;
   PPProblem pr[PP_MAXP];
-  int64_t Ms[PP_MAXP], Ns[PP_MAXP], Ks[PP_MAXP];
+  int64_t Ms[PP_MAXP], Ns[PP_MAXP], Ks[PP_MAXP], ldas[PP_MAXP], ldbs[PP_MAXP];
   int cfg = PP_NONE;
   for (int i = 0; one && i < n; ++i) {
     const mafed_gemm_problem& q = problems[i];
@@ -709,13 +709,12 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
     GemmEpi epi{q.bias, q.epilogue & ~MAFED_EPI_RES1_BF16, q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
     one = q.A && q.B && q.C && q.M > 0 && (c_dtype == MAFED_F32 || q.beta == 0.f) && !(q.colsum && q.beta != 0.f) &&
           pp_fill_problem(pr[i], a_ks, b_ks, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, epi, q.colsum);
-    Ms[i] = q.M; Ns[i] = q.N; Ks[i] = q.K;
-    if (one) {
-      // one configuration for the whole group: the one the first problem picks must tile the others too
-      const int c = gemm_pp_pick(a_ks, b_ks, c_dtype, q.M, q.N, q.K, q.lda, q.ldb, i == 0 ? g_gemm_pp_force : cfg);
-      if (i == 0) cfg = c;
-      one = c != PP_NONE && c == cfg;
-    }
+    Ms[i] = q.M; Ns[i] = q.N; Ks[i] = q.K; ldas[i] = q.lda; ldbs[i] = q.ldb;
+  }
+  if (one) {
+    double fill = 0.0;
+    cfg = gemm_pp_pick(a_ks, b_ks, c_dtype, n, Ms, Ns, Ks, ldas, ldbs, g_gemm_pp_force, &fill);
+    one = cfg != PP_NONE && (g_gemm_pp_force >= 0 || fill >= 0.7);
   }
   if (one) {
     const int rc = gemm_pp_launch(cfg, a_ks, b_ks, c_dtype, pr, n, Ms, Ns, Ks, as_stream(stream));
@@ -782,13 +781,11 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
   if ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0) {
     PPProblem pr;
     if (pp_fill_problem(pr, a_ks, b_ks, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, epi, colsum)) {
-      int pcfg = gemm_pp_pick(a_ks, b_ks, c_dtype, M, N, K, lda, ldb, g_gemm_pp_force);
-      if (pcfg != PP_NONE && g_gemm_pp_force < 0) {
-        // one persistent block per CU: a tile count that leaves the last round of the 256 CUs mostly empty (a single weight gradient:
-        // 128 tiles) is the 128 x 128 kernel's job, or that of a grouped launch
-        const int64_t tiles = (M / (pcfg == PP_128x256 ? 128 : 144)) * (N / 256), rounds = (tiles + 255) / 256;
-        if (tiles * 100 < rounds * 256 * 85) pcfg = PP_NONE;
-      }
+      double fill = 0.0;
+      int pcfg = gemm_pp_pick(a_ks, b_ks, c_dtype, 1, &M, &N, &K, &lda, &ldb, g_gemm_pp_force, &fill);
+      // one persistent block per CU: a tile count that leaves the last round of the 256 CUs mostly empty (a single weight gradient:
+      // 64 - 128 tiles) is the 128 x 128 kernel's job, or that of a grouped launch
+      if (pcfg != PP_NONE && g_gemm_pp_force < 0 && fill < 0.85) pcfg = PP_NONE;
       if (pcfg != PP_NONE) {
         rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st);
         if (rc != MAFED_OK) return rc;

@@ -34,10 +34,12 @@ struct PPArgs {
 };
 
 // tile configurations of the ping-pong kernel
-enum PPConfig { PP_NONE = -1, PP_144x256 = 0, PP_128x256 = 1, PP_NCFG = 2 };
+enum PPConfig { PP_NONE = -1, PP_144x256 = 0, PP_128x256 = 1, PP_256x256 = 2, PP_NCFG = 3 };
 
-// picks a configuration for one problem (or PP_NONE when no configuration tiles the shape exactly / the mode is not instantiated)
-int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int force_cfg);
+// picks a configuration for a launch of n problems (PP_NONE when no configuration tiles every shape / the mode is not instantiated);
+// *fill_out = tiles / (rounds x 256 CUs) of the chosen configuration
+int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t* Ms, const int64_t* Ns, const int64_t* Ks, const int64_t* ldas,
+                 const int64_t* ldbs, int force_cfg, double* fill_out);
 // launches `n` problems (same layouts / output type / configuration) as ONE persistent grid
 int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,
                    const int64_t* Ks, hipStream_t st);

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "gemm_pp.h"
+#include "gemm_pp_epilogue.h"
 #include "gemm_tiles.h"
 
 namespace mafed {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   static_assert(A_PW + B_PW == (NPH == 3 ? 7 : 6), "issue groups: 3+2+2 (3+2+1 for waves 2..7 of a 144-row tile) / 3+3 pieces per wave");
   constexpr int RBB = TN * 2;                   // bytes per k-row of the [k][TN] image
   constexpr int NPAIR = NT / 2;
-  constexpr int NST = PAIR ? MT * NPAIR : MT * NT;   // C stores per wave per tile: lower bound of the epilogue's VMEM operations
+  constexpr int NST = PPEpilogue<MT, NT, CT>::NST;   // C stores per wave per tile: lower bound of the epilogue's VMEM operations
   constexpr int NA_RD = A_KS ? MTP : 2, NB_RD = B_KS ? (PAIR ? NPAIR : NT) : 2, NVB = (PAIR && !B_KS) ? 4 : 2;
   (void)args_by_value;
 
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
   // Problem fields live in SGPRs and are re-read from the kernarg table only when a tile belongs to another problem.
   // `dq` = the problem of the DMA stream's tile, `cq` = the problem of the tile being computed.
   struct DmaProb { const char* A; const char* B; uint32_t lda, ldb; int nkt, tiles_m, tiles_n, tile_begin; } dq;
-  struct EpiProb { void* C; const float* bias; void* aux; const void* res1; const float* res2; float* colsum; int64_t ldc; float beta; int mode, res1_bf16, nkt; } cq;
+  PPEpiProb cq;
   const int GM = args->group_m, nprobs = args->nprobs;
   auto load_dq = [&](int pi) {
     dq.A = reinterpret_cast<const char*>(args->p[pi].A); dq.B = reinterpret_cast<const char*>(args->p[pi].B);
@@ -441,177 +442,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
     if constexpr (NSTG == 3) { const int t = st0; st0 = st1; st1 = st2; st2 = t; }
   };
 
-  // ---- epilogue: straight from the accumulators, 64-byte row segments per store instruction -------------------------------------
-  // Column group outermost (8 columns of a bf16 C, 4 of an fp32 C: one store instruction = 16 rows x 64 bytes), row fragments inside,
-  // the operands the epilogue READS (saved pre-activation of GELU', residuals, old C) fetched PD row fragments ahead of the stores.
-  // MODE / HSRC / FSRC are compile-time per instantiation (dispatched on the problem's epilogue below): HSRC = bf16 operand slot
-  // (0 none, 1 aux of GELU', 2 bf16 res1), FSRC = fp32 operand slot (0 none, 1 res2, 2 old C for beta != 0).
-  constexpr int NG = PAIR ? NPAIR : NT;
-  constexpr int GW = PAIR ? 8 : 4;
-  constexpr int GSTEP = PAIR ? 32 : 16;
-  auto epilogue_fast = [&](auto mode_c, auto hsrc_c, auto fsrc_c, int pi, int tm, int tn) {
-    constexpr int MODE = decltype(mode_c)::value, HSRC = decltype(hsrc_c)::value, FSRC = decltype(fsrc_c)::value;
-    CT* __restrict__ C = reinterpret_cast<CT*>(cq.C);
-    const float* __restrict__ bias = cq.bias;
-    CT* aux = reinterpret_cast<CT*>(cq.aux);
-    const bf16_t* res1 = reinterpret_cast<const bf16_t*>(cq.res1);
-    const float* res2 = cq.res2;
-    float* colsum = cq.colsum;
-    const int64_t ldc = cq.ldc;
-    const float beta = cq.beta;
-    const int64_t row0 = (int64_t)tm * TM + li;
-    const int64_t col0 = (int64_t)tn * TN + wave * NT * 16 + (PAIR ? 8 * q4 : 4 * q4);
-    struct Pre { uint4 h; float4 f0, f1; };
-    constexpr int PD = 3;
-    float* scr = reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int64_t cg = col0 + g * GSTEP;
-      float bv[GW], cs[GW];
-      if (bias) {
-        if constexpr (PAIR) load8(bias + cg, bv);
-        else { const float4 b = load4(bias + cg); bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < GW; ++e) bv[e] = 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < GW; ++e) cs[e] = 0.f;
-      auto fetch = [&](int mt, Pre& p) {
-        const int64_t o = (row0 + mt * 16) * ldc + cg;
-        if constexpr (HSRC != 0) {
-          const bf16_t* src = HSRC == 1 ? reinterpret_cast<const bf16_t*>(aux) : res1;
-          if constexpr (PAIR) p.h = *reinterpret_cast<const uint4*>(src + o);
-          else { const uint2 t = *reinterpret_cast<const uint2*>(src + o); p.h = make_uint4(t.x, t.y, 0u, 0u); }
-        }
-        if constexpr (FSRC != 0) {
-          const float* src = FSRC == 1 ? res2 : reinterpret_cast<const float*>(C);
-          p.f0 = load4(src + o);
-          if constexpr (PAIR) p.f1 = load4(src + o + 4);
-        }
-      };
-      Pre pre[MT];
-      if constexpr (HSRC != 0 || FSRC != 0) {
-#pragma unroll
-        for (int mt = 0; mt < PD && mt < MT; ++mt) fetch(mt, pre[mt]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if constexpr (HSRC != 0 || FSRC != 0) {
-          if (mt + PD < MT) fetch(mt + PD, pre[mt + PD]);
-        }
-        const int64_t o = (row0 + mt * 16) * ldc + cg;
-        float v[GW];
-        if constexpr (PAIR) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = acc[2 * g][mt][e]; v[4 + e] = acc[2 * g + 1][mt][e]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[g][mt][e];
-        }
-#pragma unroll
-        for (int e = 0; e < GW; ++e) v[e] += bv[e];
-        float hv[GW];
-        if constexpr (HSRC != 0) {
-          if constexpr (PAIR) unpack8(pre[mt].h, hv);
-          else {
-            hv[0] = __uint_as_float(pre[mt].h.x << 16); hv[1] = __uint_as_float(pre[mt].h.x & 0xffff0000u);
-            hv[2] = __uint_as_float(pre[mt].h.y << 16); hv[3] = __uint_as_float(pre[mt].h.y & 0xffff0000u);
-          }
-        }
-        if constexpr (MODE == MAFED_EPI_GELU) {
-          if (aux) {
-            if constexpr (PAIR) store8(aux + o, v);
-            else store4(aux + o, make_float4(v[0], v[1], v[2], v[3]));
-          }
-#pragma unroll
-          for (int e = 0; e < GW; e += 2) {
-            const f32x2 r = gelu_erf_fast2((f32x2){v[e], v[e + 1]});
-            v[e] = r[0]; v[e + 1] = r[1];
-          }
-        } else if constexpr (MODE == MAFED_EPI_GELU_BWD) {
-          static_assert(MODE != MAFED_EPI_GELU_BWD || HSRC == 1, "GELU' reads the saved pre-activation from the bf16 slot");
-#pragma unroll
-          for (int e = 0; e < GW; e += 2) {
-            const f32x2 r = gelu_erf_grad_fast2((f32x2){hv[e], hv[e + 1]});
-            v[e] *= r[0]; v[e + 1] *= r[1];
-          }
-        }
-        if constexpr (HSRC == 2) {
-#pragma unroll
-          for (int e = 0; e < GW; ++e) v[e] += hv[e];
-        }
-        if constexpr (FSRC == 1) {
-          v[0] += pre[mt].f0.x; v[1] += pre[mt].f0.y; v[2] += pre[mt].f0.z; v[3] += pre[mt].f0.w;
-          if constexpr (PAIR) { v[4] += pre[mt].f1.x; v[5] += pre[mt].f1.y; v[6] += pre[mt].f1.z; v[7] += pre[mt].f1.w; }
-        }
-        if constexpr (FSRC == 2 && !PAIR) {
-          v[0] += beta * pre[mt].f0.x; v[1] += beta * pre[mt].f0.y; v[2] += beta * pre[mt].f0.z; v[3] += beta * pre[mt].f0.w;
-        }
-        if constexpr (PAIR) store8(C + o, v);
-        else store4(C + o, make_float4(v[0], v[1], v[2], v[3]));
-        if (colsum) {
-#pragma unroll
-          for (int e = 0; e < GW; ++e) cs[e] += v[e];
-        }
-      }
-      if (colsum) {
-        // fold the 16 rows of a lane group; the wave's NT*16 column sums go through a wave-private LDS strip
-#pragma unroll
-        for (int e = 0; e < GW; ++e) {
-          float s = cs[e];
-          s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-          if (li == 0) scr[g * GSTEP + GW * q4 + e] = s;
-        }
-      }
-    }
-    if (colsum) {
-      // one atomic instruction of contiguous floats per wave and tile (full-rate shape of MI355X_MICROARCH "Global float atomics")
-      __builtin_amdgcn_wave_barrier();
-      if (lane < NT * 16) atomicAdd(colsum + (int64_t)tn * TN + wave * NT * 16 + lane, scr[lane]);
-      __builtin_amdgcn_wave_barrier();
-    }
-  };
-  // any other epilogue combination: the in-place operand loads of gemm_epilogue.h (no prefetch, no fused column sums)
-  auto epilogue_generic = [&](int pi, int tm, int tn) {
-    GemmEpi e;
-    e.bias = cq.bias; e.mode = cq.mode; e.aux = cq.aux;
-    e.res1 = reinterpret_cast<const float*>(cq.res1); e.res2 = cq.res2; e.res1_bf16 = cq.res1_bf16;
-    e.beta = cq.beta; e.ldc = cq.ldc; e.colsum = nullptr;
-    CT* C = reinterpret_cast<CT*>(cq.C);
-    const int64_t row0 = (int64_t)tm * TM + li;
-    const int64_t col0 = (int64_t)tn * TN + wave * NT * 16 + (PAIR ? 8 * q4 : 4 * q4);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if constexpr (PAIR) {
-          float v[8];
-#pragma unroll
-          for (int x = 0; x < 4; ++x) { v[x] = acc[2 * g][mt][x]; v[4 + x] = acc[2 * g + 1][mt][x]; }
-          epilogue_store8<CT>(e, C, row0 + mt * 16, col0 + g * GSTEP, v);
-        } else {
-          epilogue_store4<CT, true>(e, C, row0 + mt * 16, col0 + g * GSTEP, make_float4(acc[g][mt][0], acc[g][mt][1], acc[g][mt][2], acc[g][mt][3]));
-        }
-      }
-  };
-  auto epilogue = [&](int pi, int tm, int tn) {
-    using std::integral_constant;
-    const int mode = cq.mode;
-    const bool r1 = cq.res1 != nullptr, r1h = r1 && cq.res1_bf16, r2 = cq.res2 != nullptr;
-    const bool bt = cq.beta != 0.f;
-    if (mode == MAFED_EPI_NONE && !r1 && !r2 && !bt)
-      epilogue_fast(integral_constant<int, MAFED_EPI_NONE>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, pi, tm, tn);
-    else if (mode == MAFED_EPI_GELU && !r1 && !r2 && !bt)
-      epilogue_fast(integral_constant<int, MAFED_EPI_GELU>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, pi, tm, tn);
-    else if (PAIR && mode == MAFED_EPI_GELU_BWD && !r1 && !r2 && !bt)
-      epilogue_fast(integral_constant<int, PAIR ? MAFED_EPI_GELU_BWD : MAFED_EPI_NONE>{}, integral_constant<int, PAIR ? 1 : 0>{}, integral_constant<int, 0>{}, pi, tm, tn);
-    else if (mode == MAFED_EPI_NONE && r1h && r2 && !bt)
-      epilogue_fast(integral_constant<int, MAFED_EPI_NONE>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{}, pi, tm, tn);
-    else if (!PAIR && mode == MAFED_EPI_NONE && !r1 && !r2 && bt)
-      epilogue_fast(integral_constant<int, MAFED_EPI_NONE>{}, integral_constant<int, 0>{}, integral_constant<int, PAIR ? 0 : 2>{}, pi, tm, tn);
-    else
-      epilogue_generic(pi, tm, tn);
+  // ---- epilogue (gemm_pp_epilogue.h): straight from the accumulators, 64-byte row segments per store instruction -----------------
+  auto epilogue = [&](int tm, int tn) {
+    PPEpilogue<MT, NT, CT>::run(acc, cq, (int64_t)tm * TM + li, (int64_t)tn * TN + wave * NT * 16, lane,
+                                reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64);
   };
 
   // ---- main ----------------------------------------------------------------------------------------------------------------
@@ -660,7 +494,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
       }
     }
     trace_event(1);
-    epilogue(pi, tm, tn);
+    epilogue(tm, tn);
     trace_event(2);
     first = false;
     id += G;
@@ -700,38 +534,50 @@ static int pp_launch_t(const PPArgs& a, double flops, hipStream_t st) {
   return MAFED_OK;
 }
 
+int gemm_z_launch(bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPArgs& a, double flops, hipStream_t st);   // gemm_z.hip: 256 x 256 tiles
+
 static void pp_tile_shape(int cfg, int& TM, int& TN) {
   TN = 256;
-  TM = cfg == PP_128x256 ? 128 : 144;
+  TM = cfg == PP_128x256 ? 128 : (cfg == PP_256x256 ? 256 : 144);
 }
 
-int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int force_cfg) {
-  if (K % 128 != 0 || K < 256 || N % 256 != 0) return PP_NONE;
-  if (lda % 64 != 0 || ldb % 64 != 0 || lda >= (1 << 22) || ldb >= (1 << 22)) return PP_NONE;   // 32-bit piece offsets
-  auto inst = [&](int cfg) {   // instantiated (layout, output type, configuration) combinations
-    if (a_ks && b_ks) return cfg == PP_128x256 && c_dtype == MAFED_F32;
-    if (a_ks) return false;
-    if (cfg == PP_128x256) return false;
-    if (b_ks) return c_dtype == MAFED_BF16;
-    return true;
-  };
-  auto fits = [&](int cfg) {
-    int TM, TN;
-    pp_tile_shape(cfg, TM, TN);
-    return inst(cfg) && M % TM == 0 && N % TN == 0;
-  };
-  if (force_cfg >= 0) return fits(force_cfg) ? force_cfg : PP_NONE;
-  // whole rounds of the 256 CUs first, then the larger tile (fewer operand bytes per MFMA through the L2 -> LDS path, which bounds the loop)
-  int best = PP_NONE;
-  double best_score = -1.0;
-  for (int cfg = 0; cfg < PP_NCFG; ++cfg) {
-    if (!fits(cfg)) continue;
-    int TM, TN;
-    pp_tile_shape(cfg, TM, TN);
-    const int64_t tiles = (M / TM) * (N / TN), rounds = (tiles + 255) / 256;
-    const double score = (double)tiles / (double)(rounds * 256);
-    if (score > best_score) { best_score = score; best = cfg; }
+static bool pp_instantiated(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype) {
+  if (a_ks && b_ks) return (cfg == PP_128x256 || cfg == PP_256x256) && c_dtype == MAFED_F32;
+  if (a_ks) return false;
+  if (cfg == PP_128x256) return false;
+  if (cfg == PP_256x256) return c_dtype == MAFED_BF16 || !b_ks;
+  if (b_ks) return c_dtype == MAFED_BF16;
+  return true;
+}
+
+// Configuration for a launch of n problems (PP_NONE when none tiles every problem).  Whole rounds of the 256 CUs first, then the
+// 256 x 256 kernel: it moves 32 operand bytes per MFMA cycle through the L2 -> LDS path that bounds these loops, the others 44 - 48.
+int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t* Ms, const int64_t* Ns, const int64_t* Ks, const int64_t* ldas,
+                 const int64_t* ldbs, int force_cfg, double* fill_out) {
+  for (int i = 0; i < n; ++i) {
+    if (Ks[i] % 128 != 0 || Ks[i] < 256 || Ns[i] % 256 != 0) return PP_NONE;
+    if (ldas[i] % 64 != 0 || ldbs[i] % 64 != 0 || ldas[i] >= (1 << 22) || ldbs[i] >= (1 << 22)) return PP_NONE;   // 32-bit piece offsets
   }
+  int best = PP_NONE;
+  double best_score = -1.0, best_fill = 0.0;
+  for (int cfg = 0; cfg < PP_NCFG; ++cfg) {
+    if (force_cfg >= 0 && cfg != force_cfg) continue;
+    if (!pp_instantiated(cfg, a_ks, b_ks, c_dtype)) continue;
+    int TM, TN;
+    pp_tile_shape(cfg, TM, TN);
+    int64_t tiles = 0;
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+      ok = Ms[i] % TM == 0 && Ns[i] % TN == 0;
+      tiles += (Ms[i] / TM) * (Ns[i] / TN);
+    }
+    if (!ok) continue;
+    const int64_t rounds = (tiles + 255) / 256;
+    const double fill = (double)tiles / (double)(rounds * 256);
+    const double score = fill * (cfg == PP_256x256 ? 1.2 : 1.0);
+    if (score > best_score) { best_score = score; best = cfg; best_fill = fill; }
+  }
+  if (fill_out) *fill_out = best_fill;
   return best;
 }
 
@@ -760,6 +606,7 @@ int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPP
   a.ntiles = tiles;
   // the 32 CUs of an XCD take 32 consecutive tile ids: GROUP_M row tiles x (32 / GROUP_M) column tiles form a compact patch
   a.group_m = min_tn >= 8 ? 4 : (min_tn >= 4 ? 8 : 16);
+  if (cfg == PP_256x256) return gemm_z_launch(a_ks, b_ks, c_dtype, a, flops, st);
 #define PP_GO(MT, NT, NPH, NSTG, AKS, BKS, CT) return pp_launch_t<MT, NT, NPH, NSTG, AKS, BKS, CT>(a, flops, st)
   const bool f32 = c_dtype == MAFED_F32;
   if (a_ks && b_ks) {

@@ -48,9 +48,11 @@ class forced:
 
 
 # (cfg, tA, tB, out dtype): the instantiated combinations (gemm_pp_launch)
-# configuration 0 = 144 x 256 tiles (forward / dX), 1 = 128 x 256 tiles (dW: both operands reduction-major)
-COMBOS = [(0, False, True, BF), (0, False, True, F32), (0, False, False, BF), (1, True, False, F32)]
-TM = {0: 144, 1: 128}
+# configuration 0 = 144 x 256 tiles (forward / dX), 1 = 128 x 256 tiles (dW: both operands reduction-major), 2 = 256 x 256 tiles
+# (gemm_z.hip: one wave per SIMD)
+COMBOS = [(0, False, True, BF), (0, False, True, F32), (0, False, False, BF), (1, True, False, F32),
+          (2, False, True, BF), (2, False, True, F32), (2, False, False, BF), (2, True, False, F32)]
+TM = {0: 144, 1: 128, 2: 256}
 
 
 @pytest.mark.parametrize("cfg,tA,tB,od", COMBOS)
@@ -112,7 +114,7 @@ def test_pp_grouped_launch(cfg, tA, tB, od):
         assert float((q["out"].double().cpu() - r).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg", [0])
+@pytest.mark.parametrize("cfg", [0, 2])
 def test_pp_epilogues_forward(cfg):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
@@ -151,7 +153,7 @@ def test_pp_epilogues_forward(cfg):
     assert float((cg.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("cfg", [0])
+@pytest.mark.parametrize("cfg", [0, 2])
 def test_pp_gelu_backward_with_column_sums(cfg):
     """dX = dY.W with the GELU' epilogue and the fused bias gradient (column sums of the stored C)."""
     ops = _ops()
@@ -175,15 +177,16 @@ def test_pp_gelu_backward_with_column_sums(cfg):
     assert float((cs2.double().cpu() - dx.double().cpu().sum(0)).abs().max()) <= 1e-3 * float(dx.double().abs().sum(0).max())
 
 
-def test_pp_weight_gradient_accumulates():
-    """dW += dY^T.X (both operands [k][row]) through the 128x256 configuration, twice into the same buffer."""
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_pp_weight_gradient_accumulates(cfg):
+    """dW += dY^T.X (both operands [k][row]) through the 128x256 / 256x256 configurations, twice into the same buffer."""
     ops = _ops()
     g = torch.Generator().manual_seed(6)
     Kd, M, N = 1152, 512, 768
     dY, X = torch.randn(Kd, M, generator=g), torch.randn(Kd, N, generator=g)
     dYd, Xd = dY.to(DEV, BF), X.to(DEV, BF)
     G = torch.zeros(M, N, device=DEV)
-    with forced(1, 2):
+    with forced(cfg, 2):
         ops.gemm(dYd, Xd, True, False, out=G, beta=1.0)
         ops.gemm(dYd, Xd, True, False, out=G, beta=1.0)
     want = 2 * (dYd.float().cpu().double().t() @ Xd.float().cpu().double())

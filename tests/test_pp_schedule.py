@@ -36,3 +36,14 @@ def test_checker_detects_a_loosened_wait(monkeypatch):
     c = P.Cfg("144x256", False, False, True)
     monkeypatch.setattr(P, "waits_of", lambda c, wave, post, nst: {1: 6, 2: 5})
     assert P.check_schedule(c) != []
+
+
+ZCFGS = P.z_all()
+
+
+@pytest.mark.parametrize("c", ZCFGS, ids=[f"256x256-A{'ks' if c.a_ks else 'kc'}-B{'ks' if c.b_ks else 'kc'}-{'bf16' if c.pair else 'f32'}" for c in ZCFGS])
+def test_z_kernel_index_maps_and_bank_conflicts(c):
+    worst = P.z_check(c)
+    for key, ways in worst.items():
+        allowed = 2 if (key == "B:tr" and c.pair) else 1
+        assert ways <= allowed, (key, ways)

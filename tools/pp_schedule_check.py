@@ -401,5 +401,129 @@ def main():
     return 0 if ok else 1
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 4. the 256 x 256 kernel (gemm_z.hip): 2 x 2 waves of 128 x 128, 32-deep steps, [row][32 k] images of 64-byte rows.
+# ---------------------------------------------------------------------------------------------------------------------
+def z_perm(b):
+    return (4 - b) & 3
+
+
+class ZCfg:
+    def __init__(self, a_ks, b_ks, pair):
+        self.a_ks, self.b_ks, self.pair = a_ks, b_ks, pair
+        self.OPB = 256 * 64
+        self.name = "256x256"
+
+
+def z_src_elem(ks, op, byte_off):
+    e = byte_off // 2
+    return (op, e // LD, e % LD) if not ks else (op, e % LD, e // LD)
+
+
+def z_dma_fill(c):
+    lds = {}
+    for wave in range(4):
+        for lane in range(64):
+            r, ch = lane >> 2, lane & 3
+            for op, ks, base in (("A", c.a_ks, 0), ("B", c.b_ks, c.OPB)):
+                for i in range(4):
+                    pj = wave + 4 * i
+                    if not ks:
+                        so = 16 * pj * LD * 2
+                        if op == "B" and c.pair:
+                            f = z_perm((2 * wave + (r >> 3)) & 3)
+                        else:
+                            f = z_perm((r >> 2) & 3)
+                        v = r * LD * 2 + ((ch ^ f) << 4)
+                    else:
+                        so = 2 * pj * LD * 2
+                        l32 = ((lane & 31) >> 1) ^ (((2 * wave + (lane >> 5)) & 3) | ((i & 1) << 2))
+                        v = (lane >> 5) * LD * 2 + (l32 * 16 + (lane & 1) * 8) * 2
+                    for e in range(8):
+                        a = base + pj * 1024 + lane * 16 + 2 * e
+                        assert a not in lds
+                        lds[a] = z_src_elem(ks, op, so + v + 2 * e)
+    return lds
+
+
+def z_frag_addresses(c, wave, kind, t):
+    wr, wc = wave >> 1, wave & 1
+    res = []
+    ks = c.a_ks if kind == "A" else c.b_ks
+    if not ks:
+        addrs = []
+        for lane in range(64):
+            li, q4 = lane & 15, lane >> 4
+            sw = (q4 ^ z_perm((li >> 2) & 3)) << 4
+            if kind == "A":
+                addrs.append((wr * 128 + li) * 64 + sw + t * 1024)
+            elif not c.pair:
+                addrs.append(c.OPB + (wc * 128 + li) * 64 + sw + t * 1024)
+            else:
+                addrs.append(c.OPB + (wc * 128 + 8 * (li >> 2) + (li & 3)) * 64 + sw + (32 * (t >> 1) + 4 * (t & 1)) * 64)
+        res.append(("b128", addrs))
+    else:
+        for h in range(2):
+            addrs = []
+            for lane in range(64):
+                li, q4 = lane & 15, lane >> 4
+                F = (li >> 2) | ((q4 & 1) << 2)
+                kq = (8 * q4 + (li >> 2)) * 512
+                if kind == "A":
+                    base = kq + (((wr * 8 + t) ^ F) << 5) + (li & 3) * 8
+                elif not c.pair:
+                    base = c.OPB + kq + (((wc * 8 + t) ^ F) << 5) + (li & 3) * 8
+                else:
+                    base = c.OPB + kq + (((wc * 8 + 2 * (t >> 1) + ((li & 3) >> 1)) ^ F) << 5) + 16 * (li & 1) + 8 * (t & 1)
+                addrs.append(base + 4 * h * 512)
+            res.append(("tr", addrs))
+    return res
+
+
+def z_check(c):
+    lds = z_dma_fill(c)
+    worst = {}
+    for wave in range(4):
+        wr, wc = wave >> 1, wave & 1
+        for kind in ("A", "B"):
+            for t in range(8):
+                reads = z_frag_addresses(c, wave, kind, t)
+                for instr, addrs in reads:
+                    worst[kind + ":" + instr] = max(worst.get(kind + ":" + instr, 1), conflict_ways(instr, addrs))
+                if reads[0][0] == "b128":
+                    fr = [read_b128(lds, a) for a in reads[0][1]]
+                else:
+                    lo, hi = [], []
+                    for g in range(4):
+                        lo += read_tr(lds, reads[0][1][16 * g:16 * g + 16])
+                        hi += read_tr(lds, reads[1][1][16 * g:16 * g + 16])
+                    fr = [lo[l] + hi[l] for l in range(64)]
+                for lane in range(64):
+                    li = lane & 15
+                    if kind == "A":
+                        row = wr * 128 + t * 16 + li
+                    elif c.pair:
+                        row = wc * 128 + 32 * (t >> 1) + 8 * (li >> 2) + 4 * (t & 1) + (li & 3)
+                    else:
+                        row = wc * 128 + 16 * t + li
+                    for j in range(8):
+                        want = (kind, row, 8 * (lane >> 4) + j)
+                        assert fr[lane][j] == want, ("256x256", kind, wave, t, lane, j, fr[lane][j], want)
+    return worst
+
+
+def z_all():
+    return [ZCfg(a, b, p) for a, b, p in itertools.product((False, True), (False, True), (False, True))]
+
+
+def z_main():
+    for c in z_all():
+        w = z_check(c)
+        print(f"256x256 A_{'KS' if c.a_ks else 'KC'} B_{'KS' if c.b_ks else 'KC'} C_{'bf16' if c.pair else 'f32'}    index maps ok; worst bank conflict ways {w}")
+
+
 if __name__ == "__main__":
+    z_main()
     sys.exit(main())

@@ -12,8 +12,10 @@ from mafed_amd import ops, _lib
 M, N, K, tA, tB, f32 = [int(v) for v in sys.argv[1:7]] if len(sys.argv) > 6 else (9216, 4096, 1024, 0, 1, 0)
 epi = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 lib = _lib.load()
-lib.mafed_gemm_pp_set_trace.argtypes = [C.c_void_p]
-lib.mafed_gemm_pp_set_trace.restype = C.c_int
+ZK = os.environ.get("PP_TRACE_Z", "0") == "1"   # trace the 256 x 256 kernel (gemm_z.hip; force it with GEMM_BENCH_PRE=712)
+set_trace = lib.mafed_gemm_z_set_trace if ZK else lib.mafed_gemm_pp_set_trace
+set_trace.argtypes = [C.c_void_p]
+set_trace.restype = C.c_int
 for pv in os.environ.get("GEMM_BENCH_PRE", "").split(","):
     if pv:
         lib.mafed_gemm_set_variant(int(pv))
@@ -29,7 +31,7 @@ for _ in range(3):
     ops.gemm(A, B, bool(tA), bool(tB), out=out, beta=beta, **kw)
 REC = 240
 buf = torch.zeros(8 * (REC * 2 + 1), dtype=torch.int64, device="cuda")
-assert lib.mafed_gemm_pp_set_trace(buf.data_ptr()) == 0
+assert set_trace(buf.data_ptr()) == 0
 n0 = lib.mafed_gemm_pp_launches()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -37,7 +39,7 @@ ops.gemm(A, B, bool(tA), bool(tB), out=out, beta=beta, **kw)
 e1.record()
 torch.cuda.synchronize()
 assert lib.mafed_gemm_pp_launches() == n0 + 1, "not the ping-pong kernel"
-lib.mafed_gemm_pp_set_trace(None)
+set_trace(None)
 print(f"traced launch: {e0.elapsed_time(e1) * 1e3:.1f} us")
 t = buf.view(8, REC * 2 + 1).cpu()
 # events: 0 interval start, 1 epilogue start, 2 epilogue end, 3 next tile decoded (or kernel end)
