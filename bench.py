@@ -31,12 +31,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# kernel arguments in device memory: shaves the per-launch dependency latency of the ~650 launches of a step (33.93 -> 33.76 ms in a
-# same-box A/B; =0 costs a millisecond).  Read by the HIP runtime when it initialises, hence before torch is imported.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-# the step's seven streams are scheduled for the runtime's default of four hardware queues (main | teacher + a dW stream | two dW streams |
-# optimiser + loader): 3 queues -> 36.6 ms, 4 -> 34.8, 5 -> 42.3, 8 -> 41.0 in one box
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+# Two HIP runtime options are read when the runtime initialises, hence before torch is imported: they are this benchmark's settings
+# (flags below, an exported variable wins over the flag's default) and the JSON line records what was in force.
+#   HIP_FORCE_DEV_KERNARG=1  kernel arguments in device memory: shaves the per-launch dependency latency of the ~600 launches of a step
+#                            (33.93 -> 33.76 ms in a same-box A/B); --no-dev-kernarg leaves the runtime's default
+#   GPU_MAX_HW_QUEUES=4      the step's streams are scheduled for four hardware queues (main | teacher + a dW stream | two dW streams |
+#                            optimiser + loader): 3 queues -> 36.6 ms, 4 -> 34.8, 5 -> 42.3, 8 -> 41.0 in one box; --hw-queues N overrides
+def _early_flag(name, default=None, is_bool=False):
+    for i, a in enumerate(sys.argv[1:], 1):
+        if a == name:
+            return True if is_bool else (sys.argv[i + 1] if i + 1 < len(sys.argv) else default)
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return False if is_bool else default
+
+
+_hwq = _early_flag("--hw-queues")
+if _hwq is not None:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(_hwq))
+else:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+if not _early_flag("--no-dev-kernarg", is_bool=True):
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+_rccl_ch = _early_flag("--rccl-channels")
+if _rccl_ch is not None:  # RCCL reads these when the communicator is created
+    os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(int(_rccl_ch))
 
 import torch  # noqa: E402
 
@@ -56,6 +75,15 @@ def algorithmic_flops_per_sample(h, L, V, P, T, dv, distill=True):
     if distill:
         total += stack * (L - 2) / L + proj
     return total
+
+
+def lm_head_rows(B, T, hint, bf16, sparse):
+    """Rows the LM head runs on for a batch of B samples: B*T dense, or B x (rows per sample of the row-sparse head, model.py) when the
+    batch carries the loader's ``max_label_rows`` hint."""
+    if not sparse or hint is None:
+        return B * T
+    rc = next((r for r in range(max(2, hint + 1), T + 1) if (B * r) % 128 == 0), None) if bf16 else max(2, hint + 1)
+    return B * rc if rc is not None and rc * 2 <= T else B * T
 
 
 def cpu_baseline(model_name, P, T, seconds_hint=20.0):
@@ -92,8 +120,28 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
         tr.step(batch, n + 1, batch)
         n += 1
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 CPU, VLPythia-{model_name}+MAFED distill step, batch {B} (of 32), {P} img + {T} txt tokens, {n} timed steps"}
+    out = {"value": round(B * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"oracle fp32 CPU, VLPythia-{model_name}+MAFED distill step, batch {B} (of 32), {P} img + {T} txt tokens, {n} timed steps"}
+    del tr, sd, tsd
+    # BASELINE.json configs[0], the reference's own CPU-runnable case, at its full size: VLPythia-160M naive finetune (no distillation),
+    # batch 4, 64 image + 16 text tokens
+    try:
+        cfg0 = R.preset("160m", num_vision_tokens=64)
+        sd0 = R.init_weights(cfg0, seed=1234)
+        b0 = R.make_batch(cfg0, 4, 16, seed=1235, pad=False)
+        tr0 = R.RefTrainer(cfg0, sd0, lr=5e-5, accumulate=1, replay_interval=4, warmup_steps=0, total_steps=1000, task_id=0)
+        tr0.step(b0, 0)
+        n0, t0 = 0, time.time()
+        while n0 < 3 or (time.time() - t0 < 6.0 and n0 < 40):
+            tr0.step(b0, n0 + 1)
+            n0 += 1
+        dt0 = time.time() - t0
+        out["configs0"] = {"value": round(4 * n0 / dt0, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+                           "sample": f"oracle fp32 CPU, VLPythia-160M naive finetune step (CE only, clip, AdamW), batch 4, 64 img + 16 txt tokens, "
+                                     f"{n0} timed steps (BASELINE.json configs[0] at full size)"}
+    except Exception as e:
+        out["configs0"] = {"value": None, "sample": f"failed: {e}"}
+    return out
 
 
 def _spawn_ranks(n: int) -> int:
@@ -156,6 +204,11 @@ def main():
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the links")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this process (default 4; read before the HIP runtime starts)")
+    ap.add_argument("--no-dev-kernarg", action="store_true", help="leave HIP_FORCE_DEV_KERNARG at the runtime's default")
+    ap.add_argument("--rccl-channels", type=int, default=None, help="N > 1: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS)")
+    ap.add_argument("--memory-size", type=int, default=4000, help="samples resident in the HBM replay memory (the reference's --memory_size)")
+    ap.add_argument("--exact-normaliser", action="store_true", help="N > 1: distillation means over the GLOBAL token counts (one small all-reduce)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -165,6 +218,7 @@ def main():
     from mafed_amd.dist import broadcast_teacher, init_from_env
     from mafed_amd.methods import HBMReplayBuffer
     from mafed_amd.profiler import KernelProfile
+    from mafed_amd.runtime_env import runtime_env
     import torch.distributed as dist
 
     if args.gemm_variant is not None:
@@ -214,15 +268,24 @@ def main():
         student.overlap_param_grads = False
     if args.dw_group_layers is not None:
         student.dw_group_layers = args.dw_group_layers
-    n_mem = 8 * B
+    # the replay memory holds --memory-size samples (the reference's memory_size = 4000, scripts/run_seed42.sh) resident in HBM: bf16 patch
+    # features [n, P, dv] (2.1 GB at 4000 x 256 x 1024) + int64 text tensors; generated on the device in chunks, rank-specific seeds
+    n_mem = max(8 * B, args.memory_size)
     gcpu = torch.Generator().manual_seed(1235 + rank)
     ids = torch.randint(1, cfg.vocab_size, (n_mem, T), generator=gcpu)
     labels = torch.full((n_mem, T), -100, dtype=torch.int64)
     labels[:, -4:] = ids[:, -4:]
-    mem_samples = {"input_ids": ids, "attention_mask": torch.ones(n_mem, T, dtype=torch.int64), "labels": labels,
-                   "patch_embeddings": torch.randn(n_mem, P, cfg.vision_hidden_size, generator=torch.Generator().manual_seed(1234 + rank))}
+    gmem = torch.Generator(device=dev).manual_seed(1234 + rank)
     mem = HBMReplayBuffer(B, dev, seed=1236 + rank)
+    chunk = 512
+    feats = torch.empty(n_mem, P, cfg.vision_hidden_size, dtype=torch.bfloat16, device=dev)
+    for lo in range(0, n_mem, chunk):
+        hi = min(n_mem, lo + chunk)
+        feats[lo:hi] = torch.randn(hi - lo, P, cfg.vision_hidden_size, generator=gmem, device=dev).to(torch.bfloat16)
+    mem_samples = {"input_ids": ids, "attention_mask": torch.ones(n_mem, T, dtype=torch.int64), "labels": labels, "patch_embeddings": feats}
     mem.add(mem_samples)
+    del feats
+    mem_small = {k: v[: 8 * B] for k, v in mem_samples.items()}   # the secondary / image legs keep a small memory of their own
     fd.mem_dataloader = mem
     conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=1, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
                                  weight_decay=0.01, optim="adamw", warmup_perc=0.1)
@@ -295,7 +358,7 @@ def main():
         tr.join()
         B2 = 16
         mem2 = HBMReplayBuffer(B2, dev, seed=2236 + rank)
-        mem2.add(mem_samples)
+        mem2.add(mem_small)
         fd.mem_dataloader = mem2
         fd.batch_size = B2
         conf2 = types.SimpleNamespace(accumulate_grad_batches=4, replay_interval=4, grad_norm=2.0, learning_rate=5e-5, betas=(0.9, 0.98),
@@ -303,7 +366,9 @@ def main():
         student.zero_grad()
         tr2 = Trainer(student, fd, conf2, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
                       bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt, incremental_norm=not args.no_incremental_norm)
-        task2 = [mem2._draw() for _ in range(4)]   # current-task micro-batches (synthetic, resident in HBM)
+        # current-task micro-batches (synthetic, resident in HBM) WITHOUT the loader's label-row hint: a task DataLoader's collate does not
+        # attach it, so the three plain-CE micro-batches run the dense LM head; the memory micro-batch keeps the hint (row-sparse head)
+        task2 = [{k: v for k, v in mem2._draw().items() if k != "max_label_rows"} for _ in range(4)]
         n_opt = max(3, args.steps // 4)
         for i in range(8):                          # two untimed optimiser steps
             tr2.step(task2[i % 4], i)
@@ -322,6 +387,9 @@ def main():
         tr2.join()
         fl2 = B2 * (3 * algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size, distill=False)
                     + algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size, distill=True))
+        # executed flops, as in the headline: the MAFED micro-batch carries the hint and runs the row-sparse head, the three task micro-batches do not
+        hr2 = lm_head_rows(B2, T, mem2.max_label_rows if mem2.attach_label_hint else None, cd == torch.bfloat16, student.sparse_lm_head)
+        fl2 -= 3.0 * 2.0 * cfg.hidden_size * cfg.vocab_size * (B2 * T - hr2)
         secondary = {"metric": "train samples/s, reference schedule: bs16 x accum4, 3 plain-CE + 1 MAFED micro-batch per optimiser step",
                      "value": round(4 * B2 * n_opt * world / dt2, 3), "unit": "samples/s", "optimizer_steps": n_opt,
                      "ms_per_optimizer_step": round(dt2 / n_opt * 1e3, 3), "samples_per_optimizer_step": 4 * B2 * world,
@@ -389,18 +457,28 @@ def main():
         samples = args.steps * B * world
         value = samples / dt
         flops_step = algorithmic_flops_per_sample(cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, P, T, cfg.vision_hidden_size) * B
-        head_rows = B * T
-        hint = getattr(mem, "max_label_rows", None)
-        if student.sparse_lm_head and hint is not None and getattr(mem, "attach_label_hint", False):
-            rc = next((r for r in range(hint + 1, T + 1) if (B * r) % 128 == 0), None) if cd == torch.bfloat16 else hint + 1
-            if rc is not None and rc * 2 <= T:
-                head_rows = B * rc
+        hint = getattr(mem, "max_label_rows", None) if getattr(mem, "attach_label_hint", False) else None
+        head_rows = lm_head_rows(B, T, hint, cd == torch.bfloat16, student.sparse_lm_head)
         flops_exec = flops_step - 3.0 * 2.0 * cfg.hidden_size * cfg.vocab_size * (B * T - head_rows)
         roof, kernels = None, None
-        if prof_step and "gemm_bf16" in prof_step:
-            gm = prof_step["gemm_bf16"]
+
+        def merged(prof, tags):   # one figure over several profiler tags: sum(work) / sum(duration)
+            rows = [prof[t] for t in tags if prof and t in prof]
+            if not rows:
+                return None
+            m = {"launches": sum(r["launches"] for r in rows), "total_ms": sum(r["total_ms"] for r in rows), "work": sum(r["work"] for r in rows)}
+            m["avg_us"] = m["total_ms"] * 1e3 / m["launches"]
+            m["achieved"] = m["work"] / (m["total_ms"] * 1e-3) / 1e12
+            m["frac"] = m["achieved"] / PEAK_BF16_TFLOPS
+            return m
+
+        # dominant kernel = the bf16 MFMA GEMM: the persistent ping-pong kernels (tag gemm_pp: gemm_pp_kernel / gemm_z_kernel) plus
+        # the shapes they do not tile, which stay on gemm_bf16_glds_kernel (tag gemm_bf16)
+        GEMM_TAGS = ("gemm_pp", "gemm_bf16")
+        g_alone, g_step = merged(prof_alone, GEMM_TAGS), merged(prof_step, GEMM_TAGS)
+        if g_alone or g_step:
             traffic, tsrc = None, None
-            for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:  # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE)
                     with open(os.path.join(ROOT, "profiles", cand)) as fp:
                         traffic = json.load(fp)["hbm_MB_per_launch"] * 1e6
@@ -408,24 +486,30 @@ def main():
                     break
                 except Exception:
                     pass
+            # `frac` is the kernels' own figure: every launch with the chip to itself (side streams off, same step, same shapes).  Inside
+            # the timed configuration several kernels share the CUs, which stretches each launch: that figure is `frac_in_step`.
+            gm = g_alone or g_step
             roof = {"bound": "mfma", "achieved": round(gm["achieved"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(gm["frac"], 4), "traffic": traffic, "traffic_source": tsrc,
-                    "kernel": "gemm_bf16_glds_kernel (every bf16 MFMA GEMM launch)",
-                    "mode": f"sum(2MNK) / sum(kernel execution time) over {N_PROF} steps of the timed configuration (side streams on: kernels "
-                            "share the chip), start/stop events on each launch = rocprofv3 --kernel-trace durations",
-                    "records": "profiles/r02_kernel_profile_timed.csv (this command with --dump-profile; rocprofv3 --kernel-trace of the same command "
-                               "is in profiles/r02_bench_kernel_stats.csv -- its host overhead delays the student's launches by ~7 ms per step, the "
-                               "streams overlap less and every kernel looks ~20 % shorter there; the single-stream figures below agree with "
-                               "profiles/r02_bench_no_overlap_kernel_stats.csv)",
+                    "kernel": "bf16 MFMA GEMM: gemm_pp_kernel + gemm_z_kernel (persistent, tag gemm_pp) and gemm_bf16_glds_kernel (tag gemm_bf16)",
+                    "mode": f"sum(2MNK) / sum(kernel execution time) over {N_PROF} steps with the side streams off (each kernel has the chip to "
+                            "itself), start/stop events on each launch = rocprofv3 --kernel-trace durations; `frac_in_step` = the same over "
+                            f"{N_PROF} steps of the timed configuration (kernels of several streams share the chip)",
+                    "records": "profiles/r03_kernel_profile_no_overlap.csv / r03_kernel_profile_timed.csv (this command with --dump-profile); "
+                               "rocprofv3 --kernel-trace --stats of the same command: profiles/r03_bench_kernel_stats.csv",
                     "launches_per_step": round(gm["launches"] / N_PROF, 1), "avg_launch_us": round(gm["avg_us"], 2),
                     "avg_gflop_per_launch": round(gm["work"] / gm["launches"] / 1e9, 3)}
-            if prof_alone and "gemm_bf16" in prof_alone:
-                g1 = prof_alone["gemm_bf16"]
-                roof["achieved_no_overlap"] = round(g1["achieved"], 2)
-                roof["frac_no_overlap"] = round(g1["frac"], 4)
-                roof["avg_launch_us_no_overlap"] = round(g1["avg_us"], 2)
+            if g_step and g_alone:
+                roof["achieved_in_step"] = round(g_step["achieved"], 2)
+                roof["frac_in_step"] = round(g_step["frac"], 4)
+                roof["avg_launch_us_in_step"] = round(g_step["avg_us"], 2)
+            for t in GEMM_TAGS:
+                r1 = prof_alone.get(t) if prof_alone else None
+                if r1:
+                    roof[f"{t}_share"] = {"launches_per_step": round(r1["launches"] / N_PROF, 1), "tflops": round(r1["achieved"], 1),
+                                          "flop_share": round(r1["work"] / gm["work"], 4)} if g_alone else None
             kernels = []
-            for tag in ("gemm_bf16", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "layernorm_fwd", "layernorm_bwd", "ce_fwd", "ce_bwd", "distill_fwd",
+            for tag in ("gemm_pp", "gemm_bf16", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "layernorm_fwd", "layernorm_bwd", "ce_fwd", "ce_bwd", "distill_fwd",
                         "adamw", "gradnorm", "embed_concat_fwd", "embed_concat_bwd", "cast", "colsum", "layernorm_bwd_reduce"):
                 a = prof_step.get(tag)
                 if not a:
@@ -447,7 +531,8 @@ def main():
                           f"{cfg.num_hidden_layers - 1}-layer per-modality MSE, clip 2.0, AdamW), {P} img + {T} txt tokens",
                           "global_batch": B * world, "per_gpu_batch": B, "seq_len": P + T, "parallelism": f"dp{world}",
                           "random_init_weights": True},
-               "ranks_joined": ranks_joined, "dist_backend": backend,
+               "ranks_joined": ranks_joined, "dist_backend": backend, "runtime_env": runtime_env(),
+               "replay_memory": {"samples": len(mem), "HBM_MB": round(sum(v.numel() * v.element_size() for v in mem.data.values() if v is not None) / 1e6, 1)},
                "step_tflops_algorithmic": round(flops_step / 1e12, 3),
                "mfma_frac_whole_step": round(flops_exec * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5)}
         if head_rows != B * T:

@@ -189,6 +189,11 @@ int mafed_embed_concat_bwd(const float* dh0, const int64_t* input_ids, int B, in
  * loss = mean_b( sum_t ce[b,t] / max(count_b, 1e-13) ).  lse fp32 [B,T] saved.  loss_out fp32 [1]. */
 int mafed_ce_fwd(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V,
                  float* lse, float* row_loss /* [B,T] scratch */, float* loss_out, void* stream);
+/* mafed_ce_fwd whose loss becomes NaN when the device flag *poison_flag is non-zero: the row-sparse LM head (mafed_label_rows) raises
+ * its overflow flag when a sample has more labelled positions than the caller's hint promised -- rows were dropped, the loss would be
+ * silently wrong -- and the step then fails loudly (NaN loss, caught by every trainer) without a host synchronisation. */
+int mafed_ce_fwd_guarded(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V,
+                         float* lse, float* row_loss, float* loss_out, const int* poison_flag, void* stream);
 /* dlogits[b,t,:] = gloss * (softmax - onehot) / (B * count_b) for valid rows, 0 otherwise (incl. t = T-1).
  * gloss_dev: device scalar (upstream dL/dloss).  dlogits may alias logits. */
 int mafed_ce_bwd(const void* logits, mafed_dtype dtype, const int64_t* labels, const float* lse, int B, int T, int64_t V,
@@ -198,7 +203,7 @@ int mafed_ce_bwd(const void* logits, mafed_dtype dtype, const int64_t* labels, c
  * s, t: fp32 [B,S,h] student / frozen-teacher hidden state of one layer; attention_mask int64 [B,T]; P image tokens.
  * One pass serves both masks: out[4] = { sum_lang d, sum_vision d, n_lang, n_vision } with
  *   mse:    d[row] = sum((s-t)^2)/h                      (_compute_mse_distillation_loss, :237-249)
- *   cosine: d[row] = 1 - cos(s,t)  (CosineEmbeddingLoss target 1, eps 1e-8 inside the norms; :226-235)
+ *   cosine: d[row] = 1 - cos(s,t)  (CosineEmbeddingLoss target 1; aten's form: cos = st / sqrt((ss + 1e-12) (tt + 1e-12)), the epsilon on the SQUARED norms; :226-235)
  * Deterministic two-stage reduction (no float atomics).  workspace >= mafed_distill_workspace_bytes(B*S). */
 size_t mafed_distill_workspace_bytes(int64_t rows);
 int mafed_distill_fwd(const float* s, const float* t, const int64_t* attention_mask, int B, int S, int P, int h,

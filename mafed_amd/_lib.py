@@ -45,6 +45,7 @@ SIGNATURES = {
     "mafed_embed_concat_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _l, _p, _p]),
     "mafed_embed_concat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _l, _p, _i, _p, _p]),
     "mafed_ce_fwd": (_i, [_p, _i, _p, _i, _i, _l, _p, _p, _p, _p]),
+    "mafed_ce_fwd_guarded": (_i, [_p, _i, _p, _i, _i, _l, _p, _p, _p, _p, _p]),
     "mafed_ce_bwd": (_i, [_p, _i, _p, _p, _i, _i, _l, _p, _p, _p]),
     "mafed_distill_workspace_bytes": (_z, [_l]),
     "mafed_distill_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _z, _p]),

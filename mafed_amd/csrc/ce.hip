@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
 }
 
 // loss = mean_b( sum_t row_loss[b,t] / max(count_b, 1e-13) ); one wave per sample, single block
+// `poison` (may be null): a device flag; non-zero turns the loss into NaN (mafed_ce_fwd_guarded)
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int B,
-                                                          int Tn, int64_t V, float* __restrict__ loss_out) {
+                                                          int Tn, int64_t V, float* __restrict__ loss_out, const int* __restrict__ poison) {
   __shared__ float sm[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.f;
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
   }
   if (lane == 0) sm[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) loss_out[0] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)B;
+  if (threadIdx.x == 0) {
+    const float l = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)B;
+    loss_out[0] = (poison && poison[0] != 0) ? __int_as_float(0x7fc00000) : l;
+  }
 }
 
 template <typename T>
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
 
 using namespace mafed;
 
-extern "C" int mafed_ce_fwd(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V, float* lse,
-                            float* row_loss, float* loss_out, void* stream) {
+static int ce_fwd_impl(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V, float* lse, float* row_loss,
+                       float* loss_out, const int* poison, void* stream) {
   MAFED_CHECK_ARG(logits && labels && lse && row_loss && loss_out, "ce_fwd: null pointer");
   MAFED_CHECK_ARG(B > 0 && T > 0 && V > 0 && V % 4 == 0, "ce_fwd: bad shape (V must be a multiple of 4)");
   hipStream_t st = as_stream(stream);
@@ -97,9 +101,20 @@ extern "C" int mafed_ce_fwd(const void* logits, mafed_dtype dtype, const int64_t
   if (dtype == MAFED_F32) launch(K_CE_FWD, ce_bytes, ce_fwd_kernel<float>, grid, block, 0, st, (const float*)logits, labels, B, T, V, lse, row_loss);
   else launch(K_CE_FWD, ce_bytes, ce_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, labels, B, T, V, lse, row_loss);
   MAFED_CHECK_LAUNCH("ce_fwd");
-  launch(K_SMALL, 0.0, ce_finalize_kernel, dim3(1), block, 0, st, row_loss, labels, B, T, V, loss_out);
+  launch(K_SMALL, 0.0, ce_finalize_kernel, dim3(1), block, 0, st, row_loss, labels, B, T, V, loss_out, poison);
   MAFED_CHECK_LAUNCH("ce_fwd(finalize)");
   return MAFED_OK;
+}
+
+extern "C" int mafed_ce_fwd(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V, float* lse,
+                            float* row_loss, float* loss_out, void* stream) {
+  return ce_fwd_impl(logits, dtype, labels, B, T, V, lse, row_loss, loss_out, nullptr, stream);
+}
+
+extern "C" int mafed_ce_fwd_guarded(const void* logits, mafed_dtype dtype, const int64_t* labels, int B, int T, int64_t V, float* lse,
+                                    float* row_loss, float* loss_out, const int* poison_flag, void* stream) {
+  MAFED_CHECK_ARG(poison_flag, "ce_fwd_guarded: null flag");
+  return ce_fwd_impl(logits, dtype, labels, B, T, V, lse, row_loss, loss_out, poison_flag, stream);
 }
 
 extern "C" int mafed_ce_bwd(const void* logits, mafed_dtype dtype, const int64_t* labels, const float* lse, int B, int T, int64_t V,

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 
 #include "../../include/mafed_hip.h"
 
@@ -36,15 +37,15 @@ void set_error(const char* fmt, ...);
 // flops for the MFMA kernels (GEMM, attention), bytes for the HBM-bound ones.
 enum KernelTag {
   K_GEMM_BF16 = 0, K_GEMM_F32, K_GEMM_SKINNY, K_ATTN_FWD, K_ATTN_BWD_DQ, K_ATTN_BWD_DKV, K_ATTN_EXACT, K_LN_FWD, K_LN_BWD, K_LN_BWD_REDUCE,
-  K_CE_FWD, K_CE_BWD, K_DISTILL_FWD, K_DISTILL_BWD, K_ADAMW, K_GRADNORM, K_EMBED_FWD, K_EMBED_BWD, K_COLSUM, K_CAST, K_EWC, K_SMALL, K_TAG_COUNT
+  K_CE_FWD, K_CE_BWD, K_DISTILL_FWD, K_DISTILL_BWD, K_ADAMW, K_GRADNORM, K_EMBED_FWD, K_EMBED_BWD, K_COLSUM, K_CAST, K_EWC, K_SMALL, K_GEMM_PP, K_TAG_COUNT
 };
-extern bool g_prof_on;
+extern std::atomic<bool> g_prof_on;   // read on every launch (caller thread and autograd's backward thread), written under the profiler's mutex
 bool prof_events(int tag, double work, hipEvent_t* e0, hipEvent_t* e1);
 
 template <typename... KArgs, typename... Args>
 inline void launch(int tag, double work, void (*kfn)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
   hipEvent_t e0, e1;
-  if (g_prof_on && prof_events(tag, work, &e0, &e1)) {
+  if (g_prof_on.load(std::memory_order_relaxed) && prof_events(tag, work, &e0, &e1)) {
     hipExtLaunchKernelGGL(kfn, grid, block, (uint32_t)lds, st, e0, e1, 0, static_cast<KArgs>(args)...);
     return;
   }

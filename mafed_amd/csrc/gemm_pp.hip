@@ -66,9 +66,16 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
 
 __device__ __forceinline__ int pp_f2(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }                 // [k][64] image: 32-byte chunk XOR
 
+// Register budget: two waves per SIMD of 224 registers leave 64 of the SIMD's 512 to a third wave, so that the AdamW / LayerNorm /
+// distillation kernels of the step's other streams (51 - 59 registers, no LDS) run BESIDE a persistent GEMM block instead of waiting
+// for it.  (amdgpu_num_vgpr counts half-registers of the unified VGPR + AGPR file on gfx950: N caps the kernel at 2 N.)
+#ifndef PP_VGPR_CAP
+#define PP_VGPR_CAP 256
+#endif
+
 // MT x NT fragments of 16 x 16 per wave (wave tile MT*16 x NT*16, block tile MT*16 x 8*NT*16), NPH phases per K-tile, NSTG stages.
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(PPArgs args_by_value) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2))) void gemm_pp_kernel(PPArgs args_by_value) {
   constexpr int TM = MT * 16, TN = 8 * NT * 16;
   constexpr int MTP = MT / NPH;                 // A row fragments per phase
   static_assert(MT % NPH == 0 && TN == 256 && NT == 2, "1 x 8 waves of MT*16 x 32, 256 columns");
@@ -530,7 +537,7 @@ static int pp_launch_t(const PPArgs& a, double flops, hipStream_t st) {
     attr_set = true;
   }
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
-  launch(K_GEMM_BF16, flops, kfn, dim3((unsigned)grid), dim3(512), LDS, st, a);
+  launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(512), LDS, st, a);
   return MAFED_OK;
 }
 

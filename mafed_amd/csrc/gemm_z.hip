@@ -345,7 +345,7 @@ static int z_launch_t(const PPArgs& a, double flops, hipStream_t st) {
     attr_set = true;
   }
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
-  launch(K_GEMM_BF16, flops, kfn, dim3((unsigned)grid), dim3(256), LDS, st, a);
+  launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(256), LDS, st, a);
   return MAFED_OK;
 }
 

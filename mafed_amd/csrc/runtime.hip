@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 #include <vector>
 
 namespace mafed {
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 namespace {
 struct ProfRec { int tag; double work; hipEvent_t e0, e1; };
 std::mutex g_prof_mu;                 // launches come from the caller's thread AND from autograd's backward thread
@@ -28,12 +28,12 @@ size_t g_prof_cap = 0;
 const char* const kTagNames[K_TAG_COUNT] = {
     "gemm_bf16", "gemm_f32", "gemm_skinny", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_exact", "layernorm_fwd", "layernorm_bwd",
     "layernorm_bwd_reduce", "ce_fwd", "ce_bwd", "distill_fwd", "distill_bwd", "adamw", "gradnorm", "embed_concat_fwd", "embed_concat_bwd",
-    "colsum", "cast", "ewc", "small"};
+    "colsum", "cast", "ewc", "small", "gemm_pp"};
 }  // namespace
 
 bool prof_events(int tag, double work, hipEvent_t* e0, hipEvent_t* e1) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof_on || g_prof_recs.size() >= g_prof_cap) return false;  // a full profile degrades to plain launches
+  if (!g_prof_on.load(std::memory_order_relaxed) || g_prof_recs.size() >= g_prof_cap) return false;  // a full profile degrades to plain launches
   const size_t i = g_prof_recs.size();
   *e0 = g_prof_pool[2 * i];
   *e1 = g_prof_pool[2 * i + 1];
@@ -46,6 +46,9 @@ extern "C" int mafed_prof_begin(int max_records) {
   using namespace mafed;
   MAFED_CHECK_ARG(max_records > 0 && max_records <= (1 << 22), "prof_begin: max_records %d out of range", max_records);
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  // one profile at a time: the event pool and the record list are process-wide, a second begin would re-use events the open
+  // profile has handed out
+  if (g_prof_on.load(std::memory_order_relaxed)) { set_error("prof_begin: a profile is already open (close it with mafed_prof_end)"); return MAFED_EINVAL; }
   while (g_prof_pool.size() < (size_t)2 * max_records) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) { set_error("prof_begin: hipEventCreate failed"); return MAFED_ELAUNCH; }
@@ -53,13 +56,13 @@ extern "C" int mafed_prof_begin(int max_records) {
   }
   g_prof_recs.clear();
   g_prof_cap = (size_t)max_records;
-  g_prof_on = true;
+  g_prof_on.store(true, std::memory_order_release);
   return MAFED_OK;
 }
 
 extern "C" int mafed_prof_end(void) {
   std::lock_guard<std::mutex> lk(mafed::g_prof_mu);
-  mafed::g_prof_on = false;
+  mafed::g_prof_on.store(false, std::memory_order_release);
   return MAFED_OK;
 }
 

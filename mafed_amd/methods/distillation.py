@@ -199,14 +199,18 @@ class FeatureDistillation(CLStrategy):
         n_ex = batch["input_ids"].size(0)
         do_replay = self.replay_coeff > 0 and self.task_id > 0
         pv = batch.get("pixel_values")
+        ready = getattr(self.mem_dataloader, "last_ready_event", None)
         if "patch_embeddings" not in batch and torch.is_tensor(pv) and pv.dim() == 4 and hasattr(model, "get_patch_embeddings"):
             # images in the memory batch: ONE pass through the frozen tower serves student and teacher (upstream encodes the
             # same images twice per step, distillation.py:91 and :222 -- the teacher's deep-copied tower holds the same weights)
             with torch.no_grad():
                 batch["patch_embeddings"] = model.get_patch_embeddings(pv)
+            # the features were just written on THIS stream: the loader's event says nothing about them, the teacher's stream has
+            # to wait for everything queued here (an event recorded after the tower), not for the loader
+            ready = None
         if self.distillation_coeff != 0:
             # frozen-teacher forward on a second HIP stream, concurrent with the student's
-            self._prefetch_teacher(batch, getattr(self.mem_dataloader, "last_ready_event", None))
+            self._prefetch_teacher(batch, ready)
         hooked = self._install_early_sums(model, batch)
         try:
             output = model(**batch, compute_loss=do_replay, output_hidden_states=True, return_dict=True)

@@ -625,17 +625,19 @@ class VLPythiaForCausalLM(nn.Module):
         # the VQA batches, i.e. 256 of 1024 rows at B = 32 (Rc = slots per sample incl. the unlabelled last one, B * Rc a tile multiple)
         Rc = None
         if train and labels is not None and label_rows_hint is not None:
-            need = int(label_rows_hint) + 1
+            need = max(2, int(label_rows_hint) + 1)   # (slots per sample incl. the unlabelled last one; a hint of 0 still gets two)
             Rc = need if cd == torch.float32 else next((r for r in range(need, T + 1) if (B * r) % 128 == 0), None)  # (the MFMA tiles want whole 128-row tiles)
             if Rc is not None and Rc * 2 > T:
                 Rc = None   # not worth it
         if Rc is not None:
             ros, sor, labels_c, ov = ops.label_rows(labels, Rc)
-            self.last_label_overflow = ov   # device flag: 1 if a sample had more labelled positions than the hint promised
+            # device flag: 1 if a sample had more labelled positions than the hint promised -- rows were dropped; the CE below then
+            # returns NaN (no host synchronisation: the step fails loudly instead of training on a wrong loss)
+            self.last_label_overflow = ov
             lnf_c = ops.gather_rows(lnf, ros)
             logits = ops.gemm(lnf_c, w("embed_out.weight"), False, True).view(B, Rc, cfg.vocab_size)
             sv["logits"] = logits
-            loss, lse_ce = ops.ce_fwd(logits, labels_c)
+            loss, lse_ce = ops.ce_fwd(logits, labels_c, poison=ov)
             sv["loss"], sv["ce_lse"] = loss, lse_ce
             sv["sparse_head"] = (sor, labels_c)
             sv["final"] = (xt, lnf_c, fmean, frstd)

@@ -291,15 +291,21 @@ def embed_concat_bwd(dh0, input_ids, B, P, T, h, V, d_embed_in: Optional[torch.T
     return d_image
 
 
-def ce_fwd(logits: torch.Tensor, labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """logits [B,T,V] (text positions), labels [B,T] -> (loss[1], lse[B,T])"""
+def ce_fwd(logits: torch.Tensor, labels: torch.Tensor, poison: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """logits [B,T,V] (text positions), labels [B,T] -> (loss[1], lse[B,T]).  ``poison`` (int32 [1], device): a non-zero flag turns the
+    loss into NaN (mafed_ce_fwd_guarded: the row-sparse head's overflow flag)."""
     B, T, V = logits.shape
     assert logits.is_contiguous() and labels.is_contiguous() and labels.dtype == torch.int64
     lse = torch.empty((B, T), dtype=torch.float32, device=logits.device)
     row_loss = torch.empty((B, T), dtype=torch.float32, device=logits.device)
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-    check(_lib.load().mafed_ce_fwd(_ptr(logits), _dt(logits), _ptr(labels), B, T, V, _ptr(lse), _ptr(row_loss), _ptr(loss), _stream()),
-          "mafed_ce_fwd")
+    if poison is None:
+        check(_lib.load().mafed_ce_fwd(_ptr(logits), _dt(logits), _ptr(labels), B, T, V, _ptr(lse), _ptr(row_loss), _ptr(loss), _stream()),
+              "mafed_ce_fwd")
+    else:
+        assert poison.dtype == torch.int32 and poison.numel() == 1
+        check(_lib.load().mafed_ce_fwd_guarded(_ptr(logits), _dt(logits), _ptr(labels), B, T, V, _ptr(lse), _ptr(row_loss), _ptr(loss),
+                                               _ptr(poison), _stream()), "mafed_ce_fwd_guarded")
     return loss, lse
 
 

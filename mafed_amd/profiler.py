@@ -22,7 +22,7 @@ from mafed_amd import _lib
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_F32_MATRIX_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-MFMA_TAGS = {"gemm_bf16": PEAK_BF16_TFLOPS, "gemm_skinny": PEAK_BF16_TFLOPS, "attn_fwd": PEAK_BF16_TFLOPS, "attn_bwd_dq": PEAK_BF16_TFLOPS,
+MFMA_TAGS = {"gemm_bf16": PEAK_BF16_TFLOPS, "gemm_pp": PEAK_BF16_TFLOPS, "gemm_skinny": PEAK_BF16_TFLOPS, "attn_fwd": PEAK_BF16_TFLOPS, "attn_bwd_dq": PEAK_BF16_TFLOPS,
              "attn_bwd_dkv": PEAK_BF16_TFLOPS, "gemm_f32": PEAK_F32_MATRIX_TFLOPS}
 
 

@@ -50,3 +50,33 @@ def test_profile_capacity_degrades_to_plain_launches():
             y = ops.cast(x, torch.bfloat16)
     assert len(kp.records()) == 2
     assert torch.equal(y, x.to(torch.bfloat16))
+
+
+def test_overlapping_profiles_are_rejected():
+    """The event pool and record list are process-wide: a second profile opened while one is running would hand out the
+    first one's events, so mafed_prof_begin refuses it (and the open profile keeps working)."""
+    from mafed_amd import ops
+    from mafed_amd.profiler import KernelProfile
+    x = torch.randn(64, 256, device=DEV)
+    with KernelProfile(max_records=8) as outer:
+        ops.cast(x, torch.bfloat16)
+        with pytest.raises(RuntimeError, match="already open"):
+            with KernelProfile(max_records=8):
+                pass
+        ops.cast(x, torch.bfloat16)
+    assert [r[0] for r in outer.records()] == ["cast", "cast"]
+    with KernelProfile(max_records=8) as again:      # closed profiles can be followed by new ones
+        ops.cast(x, torch.bfloat16)
+    assert len(again.records()) == 1
+
+
+def test_persistent_gemm_launches_carry_their_own_tag():
+    from mafed_amd import ops
+    from mafed_amd.profiler import KernelProfile
+    g = torch.Generator(device=DEV).manual_seed(0)
+    A = torch.randn(9216, 1024, device=DEV, generator=g).to(torch.bfloat16)
+    W = torch.randn(4096, 1024, device=DEV, generator=g).to(torch.bfloat16)
+    with KernelProfile(max_records=8) as kp:
+        ops.gemm(A, W, False, True)
+    (tag, work, ms), = kp.records()
+    assert tag == "gemm_pp" and work == 2.0 * 9216 * 4096 * 1024 and ms > 0

@@ -81,6 +81,27 @@ def test_sparse_head_equals_dense_head(dtype, B, T, n_ans, ragged):
     model.sparse_lm_head = True
 
 
+@pytest.mark.parametrize("dtype,B", [(torch.float32, 6), (torch.bfloat16, 32)])
+def test_too_small_a_hint_poisons_the_loss(dtype, B):
+    """A caller-supplied max_label_rows below the true count drops labelled rows: the device overflow flag turns the loss into NaN
+    (no host synchronisation on the step) instead of training on a wrong loss; a hint of 0 still builds a valid compact problem."""
+    import math
+    from mafed_amd import VLPythiaConfig, VLPythiaForCausalLM
+    cfg = VLPythiaConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         vision_hidden_size=32, num_vision_tokens=8)
+    model = VLPythiaForCausalLM(cfg, compute_dtype=dtype, device=DEV, seed=5)
+    batch = _batch(cfg, B, 16, 3, seed=2, ragged=False)
+    good = model(**batch, max_label_rows=3, return_dict=True)
+    assert math.isfinite(float(good.loss)) and int(model.last_label_overflow) == 0
+    for hint in (2, 1, 0):
+        bad = model(**batch, max_label_rows=hint, return_dict=True)
+        if bad.logits is None:   # the sparse head ran
+            assert int(model.last_label_overflow) == 1
+            assert math.isnan(float(bad.loss)), f"hint {hint}: overflow must poison the loss"
+        else:                    # not worth it / no tile-aligned compact size: dense head, exact loss
+            assert abs(float(bad.loss) - float(good.loss)) <= 1e-2 * abs(float(good.loss))
+
+
 def test_replay_buffer_attaches_the_hint_and_trainer_uses_it():
     import types
     from mafed_amd import CLMethod, Trainer, VLPythiaConfig, VLPythiaForCausalLM

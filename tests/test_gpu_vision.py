@@ -115,6 +115,49 @@ def test_bf16_tower_tracks_fp32_and_replay_encodes_once():
     close(loss, float(ref_loss), 1e-3, "replay loss on image inputs")
 
 
+def test_replay_orders_the_teacher_behind_its_own_tower_pass():
+    """A loader that hands out ``last_ready_event`` AND image batches: the event covers the loader's gather, not the features
+    replay() computes on the caller's stream afterwards -- the teacher's side stream must wait for those (it used
+    to wait on the loader's event only and could read ``patch_embeddings`` before the tower had written them)."""
+    from mafed_amd import FeatureDistillation
+    cc, csd, pixels, cfg, sd, batch, g = clip_setup("c50")
+    model = build_lm(cfg, sd, torch.float32, build_tower(cc, csd, torch.float32))
+    opts = types.SimpleNamespace(tasks=["a", "b"], batch_size=pixels.shape[0], seed=1, pin_mem=False, accumulate_grad_batches=1)
+    fd = FeatureDistillation(memory_size=10, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                             distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                             gamma=0.5, distillation_layer=None)
+    fd._update_model(model)
+    fd.past_model.flat_params.mul_(1.01)
+    fd.past_model._shadow_dirty = True
+    fd.task_id = 1
+    fd.num_vision_tokens = cc.num_patches
+    mem = {k: v.to(DEV) for k, v in batch.items() if k != "patch_embeddings"}
+    mem["pixel_values"] = pixels.to(DEV)
+
+    class EventLoader:      # the HBMReplayBuffer protocol: an event that marks the handed-out batch as gathered
+        def __init__(self):
+            self.last_ready_event = None
+        def __iter__(self):
+            return self
+        def __next__(self):
+            self.last_ready_event = torch.cuda.current_stream().record_event()
+            return dict(mem)
+
+    fd.mem_dataloader = [dict(mem)]
+    ref, _ = fd.replay(model)
+    ref = float(ref)
+    fd.mem_dataloader = EventLoader()
+    big = torch.randn(8192, 8192, device=DEV)
+    for _ in range(3):
+        torch.cuda.synchronize()
+        # a long queue on the caller's stream between the loader's event and the tower pass: a teacher ordered behind the loader's
+        # event alone would run far ahead of the features
+        for _ in range(6):
+            big @ big
+        got, _ = fd.replay(model)
+        assert float(got) == pytest.approx(ref, rel=1e-6), "the teacher read features the tower had not written yet"
+
+
 def test_bidirectional_attention_at_clip_l_geometry():
     """S = 257 (16 x 16 patches + class token), D = 64: the resident bf16 MFMA kernel and the exact fp32 kernel vs torch."""
     from mafed_amd import ops
