@@ -90,16 +90,23 @@ def test_too_small_a_hint_poisons_the_loss(dtype, B):
     cfg = VLPythiaConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          vision_hidden_size=32, num_vision_tokens=8)
     model = VLPythiaForCausalLM(cfg, compute_dtype=dtype, device=DEV, seed=5)
-    batch = _batch(cfg, B, 16, 3, seed=2, ragged=False)
-    good = model(**batch, max_label_rows=3, return_dict=True)
+    n_lab, T = 5, 16          # 5 labelled positions per sample; bf16 rounds the slots per sample up to whole 128-row tiles (B = 32: 4 or 8)
+    batch = _batch(cfg, B, T, n_lab, seed=2, ragged=False)
+    good = model(**batch, max_label_rows=n_lab, return_dict=True)
     assert math.isfinite(float(good.loss)) and int(model.last_label_overflow) == 0
+    ran_sparse = 0
     for hint in (2, 1, 0):
+        need = max(2, hint + 1)
+        slots = need if dtype == torch.float32 else next(r for r in range(need, T + 1) if (B * r) % 128 == 0)
+        assert slots - 1 < n_lab, "the case must overflow"
         bad = model(**batch, max_label_rows=hint, return_dict=True)
-        if bad.logits is None:   # the sparse head ran
-            assert int(model.last_label_overflow) == 1
-            assert math.isnan(float(bad.loss)), f"hint {hint}: overflow must poison the loss"
-        else:                    # not worth it / no tile-aligned compact size: dense head, exact loss
-            assert abs(float(bad.loss) - float(good.loss)) <= 1e-2 * abs(float(good.loss))
+        ran_sparse += 1
+        assert int(model.last_label_overflow) == 1
+        assert math.isnan(float(bad.loss)), f"hint {hint}: overflow must poison the loss"
+    assert ran_sparse == 3
+    # a hint that is too LARGE only costs rows: exact loss, no flag
+    roomy = model(**batch, max_label_rows=n_lab + 2, return_dict=True)
+    assert int(model.last_label_overflow) == 0 and abs(float(roomy.loss) - float(good.loss)) <= 1e-5 * abs(float(good.loss))
 
 
 def test_replay_buffer_attaches_the_hint_and_trainer_uses_it():
