@@ -37,7 +37,7 @@ struct PPArgs {
 enum PPConfig { PP_NONE = -1, PP_144x256 = 0, PP_128x256 = 1, PP_256x256 = 2, PP_NCFG = 3 };
 
 // picks a configuration for a launch of n problems (PP_NONE when no configuration tiles every shape / the mode is not instantiated);
-// *fill_out = tiles / (rounds x 256 CUs) of the chosen configuration
+// *fill_out = tiles / (rounds x 256 CUs) of the chosen configuration x its relative loop speed (1.15 for 256 x 256)
 int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t* Ms, const int64_t* Ns, const int64_t* Ks, const int64_t* ldas,
                  const int64_t* ldbs, int force_cfg, double* fill_out);
 // launches `n` problems (same layouts / output type / configuration) as ONE persistent grid

@@ -193,18 +193,34 @@ def test_pp_weight_gradient_accumulates(cfg):
     assert float((G.double().cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
-def test_pp_is_the_automatic_choice_for_the_step_shapes():
-    """M = 9216 rows (32 x 288 tokens): the dispatcher takes the ping-pong kernel for the 410M layer products."""
+@pytest.mark.parametrize("N,K,tB", [(3072, 1024, True), (1024, 1024, True), (4096, 1024, True), (1024, 4096, True),
+                                    (1024, 3072, False), (4096, 1024, False), (1024, 4096, False)])
+def test_pp_is_the_automatic_choice_for_the_step_shapes(N, K, tB):
+    """M = 9216 rows (32 x 288 tokens): the dispatcher takes the ping-pong kernel for every 410M layer product -- forward
+    (QKV / dense / fc1 / fc2) and dX (r2 of this test only had fc1; the QKV forward fell through a fill threshold unnoticed)."""
     ops = _ops()
     lib = _lib()
     lib.mafed_gemm_set_variant(701)
     g = torch.Generator(device=DEV).manual_seed(0)
-    x = torch.randn((9216, 1024), device=DEV, generator=g).to(BF)
-    w = torch.randn((4096, 1024), device=DEV, generator=g).to(BF)
+    x = torch.randn((9216, K), device=DEV, generator=g).to(BF)
+    w = torch.randn((N, K) if tB else (K, N), device=DEV, generator=g).to(BF)
     n0 = lib.mafed_gemm_pp_launches()
-    y = ops.gemm(x, w, False, True)
+    y = ops.gemm(x, w, False, tB)
     assert lib.mafed_gemm_pp_launches() == n0 + 1
     lib.mafed_gemm_set_variant(700)
-    y0 = ops.gemm(x, w, False, True)
+    y0 = ops.gemm(x, w, False, tB)
     lib.mafed_gemm_set_variant(701)
     assert float((y.float() - y0.float()).abs().max()) <= 2e-2 * float(y0.float().abs().max())
+
+
+def test_short_reductions_stay_on_the_small_tile_kernel():
+    """The LM head's weight gradient over 256 labelled rows (K = 256): four k steps per tile do not pay for a persistent tile."""
+    ops = _ops()
+    lib = _lib()
+    lib.mafed_gemm_set_variant(701)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    d = torch.randn((256, 8192), device=DEV, generator=g).to(BF)
+    a = torch.randn((256, 1024), device=DEV, generator=g).to(BF)
+    n0 = lib.mafed_gemm_pp_launches()
+    ops.gemm(d, a, True, False, out_dtype=F32)
+    assert lib.mafed_gemm_pp_launches() == n0
