@@ -247,7 +247,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
   // restored in the same statement (cdna_hip_programming 5.7); source = uniform 64-bit base in SGPRs + per-lane 32-bit byte offset.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)smem;
 #ifndef MAFED_PP_ABL
-#define MAFED_PP_ABL 0   // tuning builds (timing only, wrong results): 1 no DMA in the K loop, 2 no fragment reads, 3 no MFMA, 4 = 1 + 2
+#define MAFED_PP_ABL 0   // tuning builds (timing only, wrong results): 1 no DMA in the K loop, 2 no fragment reads, 3 no MFMA, 4 = 1 + 2,
+                         // 5 no epilogue, 6 accumulators not cleared between tiles, 7 = 5 + 6
 #endif
   bool abl_dma_on = true;
   auto dma16 = [&](const char* sbase, uint32_t voff, uint32_t lds_dst) {
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt)
+        if (!(MAFED_PP_ABL == 6 || MAFED_PP_ABL == 7) || first) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // phase 0's fragments (K-tile 0 of this tile landed and was published before the previous tile's last barrier / the prologue's)
     read_b(smem + (NSTG == 2 ? 0 : st0), fb[0]);
     read_a(smem + (NSTG == 2 ? 0 : st0), 0, fa[0]);
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
       }
     }
     trace_event(1);
-    epilogue(tm, tn);
+    if (!(MAFED_PP_ABL == 5 || MAFED_PP_ABL == 7) || id + G >= ntiles) epilogue(tm, tn);
     trace_event(2);
     first = false;
     id += G;

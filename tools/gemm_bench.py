@@ -60,7 +60,7 @@ for name, tA, tB, m, n, k, od in SHAPES:
         ops.gemm(A, B, tA, tB, out=out, beta=beta, **kw)
         if ref is None:
             ref = out.float().clone()
-        elif v < 30 or v >= 100:
+        elif (v < 30 or v >= 100) and os.environ.get("GEMM_BENCH_NOCHECK", "0") != "1":
             err = (out.float() - ref).abs().max().item()
             assert err <= 1e-2 * ref.abs().max().item(), (name, v, err)
     times = {v: [] for v in variants}
