@@ -786,6 +786,10 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
       // one persistent block per CU: a tile count that leaves the last round of the 256 CUs mostly empty (a single weight gradient:
       // 64 - 128 tiles) is the 128 x 128 kernel's job, or that of a grouped launch
       if (pcfg != PP_NONE && g_gemm_pp_force < 0 && fill < 0.85) pcfg = PP_NONE;
+      // fp32 C with both residual operands (the 4h -> h product): the register-direct epilogue moves 64-byte (fp32) and 32-byte (bf16
+      // residual) row segments, twice the memory requests of the LDS-staged epilogue of the 128 x 128 kernel for the same bytes --
+      // 82.5 us against 78.5 for the whole product, at any prefetch depth (3 / 8 / 12 items: 82.4 / 83.0 / 82.4 us)
+      if (pcfg != PP_NONE && g_gemm_pp_force < 0 && c_dtype == MAFED_F32 && epi.res1 && epi.res2) pcfg = PP_NONE;
       if (pcfg != PP_NONE) {
         rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st);
         if (rc != MAFED_OK) return rc;

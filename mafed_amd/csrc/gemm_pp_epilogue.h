@@ -9,6 +9,10 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+#ifndef PP_EPI_PD
+#define PP_EPI_PD 8   // items (16 rows x 64 bytes per operand) the epilogue's operand loads run ahead of its stores
+#endif
+
 namespace mafed {
 
 struct PPEpiProb { void* C; const float* bias; void* aux; const void* res1; const float* res2; float* colsum; int64_t ldc; float beta; int mode, res1_bf16, nkt; };
@@ -55,43 +59,53 @@ struct PPEpilogue {
     const float beta = cq.beta;
     const int64_t col0 = colw + (PAIR ? 8 * q4 : 4 * q4);
     struct Pre { uint4 h; float4 f0, f1; };
-    constexpr int PD = 3;
+    // The items (column group g, row fragment mt) form ONE sequence, g outermost; the operands item i reads are fetched PD items
+    // ahead, across group boundaries: with 8 waves per CU and ~2 us to HBM a depth of 3 kept 36 KB in flight per CU -- the
+    // residual-add epilogue of the 4h -> h product (57 MB read) then ran 11.6 us, at PD = 8 the reads are a third of that.
+    constexpr int NI = NG * MT;
+    constexpr int PD = (HSRC != 0 || FSRC != 0) ? (NI < PP_EPI_PD ? NI : PP_EPI_PD) : 0;
+    float bv[NG][GW];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int64_t cg = col0 + g * GSTEP;
-      float bv[GW], cs[GW];
       if (bias) {
-        if constexpr (PAIR) load8(bias + cg, bv);
-        else { const float4 b = load4(bias + cg); bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w; }
+        if constexpr (PAIR) load8(bias + cg, bv[g]);
+        else { const float4 b = load4(bias + cg); bv[g][0] = b.x; bv[g][1] = b.y; bv[g][2] = b.z; bv[g][3] = b.w; }
       } else {
 #pragma unroll
-        for (int e = 0; e < GW; ++e) bv[e] = 0.f;
+        for (int e = 0; e < GW; ++e) bv[g][e] = 0.f;
       }
-#pragma unroll
-      for (int e = 0; e < GW; ++e) cs[e] = 0.f;
-      auto fetch = [&](int mt, Pre& p) {
-        const int64_t o = (row0 + mt * 16) * ldc + cg;
-        if constexpr (HSRC != 0) {
-          const bf16_t* src = HSRC == 1 ? reinterpret_cast<const bf16_t*>(aux) : res1;
-          if constexpr (PAIR) p.h = *reinterpret_cast<const uint4*>(src + o);
-          else { const uint2 t = *reinterpret_cast<const uint2*>(src + o); p.h = make_uint4(t.x, t.y, 0u, 0u); }
-        }
-        if constexpr (FSRC != 0) {
-          const float* src = FSRC == 1 ? res2 : reinterpret_cast<const float*>(C);
-          p.f0 = load4(src + o);
-          if constexpr (PAIR) p.f1 = load4(src + o + 4);
-        }
-      };
-      Pre pre[MT];
-      if constexpr (HSRC != 0 || FSRC != 0) {
-#pragma unroll
-        for (int mt = 0; mt < PD && mt < MT; ++mt) fetch(mt, pre[mt]);
+    }
+    auto fetch = [&](int idx, Pre& p) {
+      const int g = idx / MT, mt = idx % MT;
+      const int64_t o = (row0 + mt * 16) * ldc + col0 + g * GSTEP;
+      if constexpr (HSRC != 0) {
+        const bf16_t* src = HSRC == 1 ? reinterpret_cast<const bf16_t*>(aux) : res1;
+        if constexpr (PAIR) p.h = *reinterpret_cast<const uint4*>(src + o);
+        else { const uint2 t = *reinterpret_cast<const uint2*>(src + o); p.h = make_uint4(t.x, t.y, 0u, 0u); }
       }
+      if constexpr (FSRC != 0) {
+        const float* src = FSRC == 1 ? res2 : reinterpret_cast<const float*>(C);
+        p.f0 = load4(src + o);
+        if constexpr (PAIR) p.f1 = load4(src + o + 4);
+      }
+    };
+    Pre pre[NI];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if constexpr (HSRC != 0 || FSRC != 0) {
-          if (mt + PD < MT) fetch(mt + PD, pre[mt + PD]);
-        }
+    for (int i = 0; i < PD; ++i) fetch(i, pre[i]);
+    float cs[GW];
+#pragma unroll
+    for (int idx = 0; idx < NI; ++idx) {
+      const int g = idx / MT, mt = idx % MT;
+      const int64_t cg = col0 + g * GSTEP;
+      if (mt == 0) {
+#pragma unroll
+        for (int e = 0; e < GW; ++e) cs[e] = 0.f;
+      }
+      if constexpr (PD != 0) {
+        if (idx + PD < NI) fetch(idx + PD, pre[idx + PD]);
+      }
+      {
         const int64_t o = (row0 + mt * 16) * ldc + cg;
         float v[GW];
         if constexpr (PAIR) {
@@ -104,13 +118,13 @@ struct PPEpilogue {
           for (int e = 0; e < 4; ++e) v[e] = t0[e];
         }
 #pragma unroll
-        for (int e = 0; e < GW; ++e) v[e] += bv[e];
+        for (int e = 0; e < GW; ++e) v[e] += bv[g][e];
         float hv[GW];
         if constexpr (HSRC != 0) {
-          if constexpr (PAIR) unpack8(pre[mt].h, hv);
+          if constexpr (PAIR) unpack8(pre[idx].h, hv);
           else {
-            hv[0] = __uint_as_float(pre[mt].h.x << 16); hv[1] = __uint_as_float(pre[mt].h.x & 0xffff0000u);
-            hv[2] = __uint_as_float(pre[mt].h.y << 16); hv[3] = __uint_as_float(pre[mt].h.y & 0xffff0000u);
+            hv[0] = __uint_as_float(pre[idx].h.x << 16); hv[1] = __uint_as_float(pre[idx].h.x & 0xffff0000u);
+            hv[2] = __uint_as_float(pre[idx].h.y << 16); hv[3] = __uint_as_float(pre[idx].h.y & 0xffff0000u);
           }
         }
         if constexpr (MODE == MAFED_EPI_GELU) {
@@ -136,11 +150,11 @@ struct PPEpilogue {
           for (int e = 0; e < GW; ++e) v[e] += hv[e];
         }
         if constexpr (FSRC == 1) {
-          v[0] += pre[mt].f0.x; v[1] += pre[mt].f0.y; v[2] += pre[mt].f0.z; v[3] += pre[mt].f0.w;
-          if constexpr (PAIR) { v[4] += pre[mt].f1.x; v[5] += pre[mt].f1.y; v[6] += pre[mt].f1.z; v[7] += pre[mt].f1.w; }
+          v[0] += pre[idx].f0.x; v[1] += pre[idx].f0.y; v[2] += pre[idx].f0.z; v[3] += pre[idx].f0.w;
+          if constexpr (PAIR) { v[4] += pre[idx].f1.x; v[5] += pre[idx].f1.y; v[6] += pre[idx].f1.z; v[7] += pre[idx].f1.w; }
         }
         if constexpr (FSRC == 2 && !PAIR) {
-          v[0] += beta * pre[mt].f0.x; v[1] += beta * pre[mt].f0.y; v[2] += beta * pre[mt].f0.z; v[3] += beta * pre[mt].f0.w;
+          v[0] += beta * pre[idx].f0.x; v[1] += beta * pre[idx].f0.y; v[2] += beta * pre[idx].f0.z; v[3] += beta * pre[idx].f0.w;
         }
         if constexpr (PAIR) store8(C + o, v);
         else store4(C + o, make_float4(v[0], v[1], v[2], v[3]));
@@ -149,7 +163,7 @@ struct PPEpilogue {
           for (int e = 0; e < GW; ++e) cs[e] += v[e];
         }
       }
-      if (colsum) {
+      if (mt == MT - 1 && colsum) {
         // fold the 16 rows of a lane group; the wave's NT*16 column sums go through a wave-private LDS strip
 #pragma unroll
         for (int e = 0; e < GW; ++e) {
