@@ -268,6 +268,7 @@ def main():
         student.overlap_param_grads = False
     if args.dw_group_layers is not None:
         student.dw_group_layers = args.dw_group_layers
+    fd.exact_normaliser = bool(args.exact_normaliser)
     # the replay memory holds --memory-size samples (the reference's memory_size = 4000, scripts/run_seed42.sh) resident in HBM: bf16 patch
     # features [n, P, dv] (2.1 GB at 4000 x 256 x 1024) + int64 text tensors; generated on the device in chunks, rank-specific seeds
     n_mem = max(8 * B, args.memory_size)
@@ -308,6 +309,8 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     torch.cuda.synchronize()
+    if tr.reducer is not None:
+        tr.reducer.time_wait = True   # two event records per step on the compute stream (diagnostics of the N > 1 line)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -315,11 +318,20 @@ def main():
         rec = tr.step(task_batch, args.warmup + i)
     t_host = time.perf_counter() - t0  # host enqueue time (the GPU runs behind it)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0  # this rank's own time, before the barrier
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        waits = tr.reducer.exposed_wait_ms() if tr.reducer is not None else []
+        tr.reducer.time_wait = False
+        mine = torch.tensor([dt_rank / args.steps * 1e3, sum(waits) / max(1, len(waits)), max(waits) if waits else 0.0], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(x[0]), 3) for x in allr], "reducer_wait_ms_mean": [round(float(x[1]), 3) for x in allr],
+                    "reducer_wait_ms_max": [round(float(x[2]), 3) for x in allr]}
     dt = float(tmax.item())
     loss = float(rec["loss"])
     log(f"timed region: {args.steps} steps in {dt * 1e3:.1f} ms (host enqueue {t_host * 1e3:.1f} ms), loss {loss:.5f}")
@@ -541,7 +553,13 @@ def main():
             out["lm_head"] = {"rows_per_step": head_rows, "of": B * T, "step_tflops_executed": round(flops_exec / 1e12, 3)}
         if world > 1:
             out["grad_exchange"] = {"mode": args.reduce_mode, "dtype": args.grad_dtype, "bucket_mb": args.bucket_mb,
-                                    "MB_per_step": round(tr.reducer.bytes_per_step / 1e6, 1), "buckets": len(tr.reducer.buckets)}
+                                    "MB_per_step": round(tr.reducer.bytes_per_step / 1e6, 1), "buckets": len(tr.reducer.buckets),
+                                    "exact_normaliser": bool(args.exact_normaliser),
+                                    # the collectives' CU budget: RCCL runs one workgroup per channel; unset = RCCL's own choice for the topology
+                                    "rccl_channels": {"NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                                                      "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")},
+                                    # reducer_wait = time the compute stream stood still in GradReducer.wait() (0 = exchange hidden under backward)
+                                    "per_rank": per_rank}
         if roof:
             out["roofline"] = roof
         if kernels:

@@ -109,7 +109,10 @@ int mafed_layernorm_fwd(const float* x, int64_t rows, int h, float eps,
  * mafed/methods/distillation.py:237-249 backward): if teacher != NULL,
  *   dx[row,:] += inj_mul * inj_scale[row_class] * (x - teacher)   with row_class from (row % S): <P image, text-valid, pad=none
  * where inj_scale_dev = {lang, vision} = d(loss)/d(sum_lang d), d(loss)/d(sum_vision d) (coeff * weight / count * upstream grad,
- * left on the device by the loss algebra) and inj_mul = 2/h (MSE). */
+ * left on the device by the loss algebra) and inj_mul = 2/h (MSE).
+ * A NEGATIVE inj_mul selects the cosine-distance loss of mafed_distill_fwd(cosine = 1) instead (distillation_loss="cosine",
+ * mafed/methods/distillation.py:226-235):
+ *   dx[row,:] += |inj_mul| * inj_scale[row_class] * d/dx [ 1 - x.t / sqrt((x.x + 1e-12)(t.t + 1e-12)) ]     (inj_mul = -1 for the plain loss) */
 size_t mafed_layernorm_bwd_workspace_bytes(int64_t rows, int h);
 int mafed_layernorm_bwd(const void* dy1, const void* dy2, mafed_dtype dy_dtype,
                         const float* x, const float* mean, const float* rstd,

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
     if (DUAL) g2[i] = (c < h) ? load4(w2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float ls = 0.f, vs = 0.f;
-  if (teacher) { ls = inj_scale[0] * inj_mul; vs = inj_scale[1] * inj_mul; }
+  // inj_mul > 0: MSE injection inj_mul * scale * (x - teacher); inj_mul < 0: cosine-distance injection |inj_mul| * scale * d/dx [1 - cos(x, teacher)]
+  const bool inj_cos = inj_mul < 0.f;
+  if (teacher) { const float m = fabsf(inj_mul); ls = inj_scale[0] * m; vs = inj_scale[1] * m; }
   for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
     const float mu = mean[row], rs = rstd[row];
     float4 xh[NV], g[NV];
@@ -143,6 +145,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
     }
     const float mg = wave_sum(sg) / (float)h, mgx = wave_sum(sgx) / (float)h;
     const float istd = 1.0f / rs;
+    // cosine distance (mafed_distill_fwd: 1 - st / sqrt((ss + eps)(tt + eps))): d/dx = ca * teacher + cb * x, from three more row sums
+    float ca = 0.f, cb = 0.f;
+    if (teacher && inj_cos && inj != 0.f) {   // (wave-uniform: one row per wave)
+      float ss = 0.f, tt = 0.f, st = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < h) {
+          const float4 tv = rte[i];
+          const float4 xv = make_float4(mu + xh[i].x * istd, mu + xh[i].y * istd, mu + xh[i].z * istd, mu + xh[i].w * istd);
+          ss += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+          tt += (tv.x * tv.x + tv.y * tv.y) + (tv.z * tv.z + tv.w * tv.w);
+          st += (xv.x * tv.x + xv.y * tv.y) + (xv.z * tv.z + xv.w * tv.w);
+        }
+      }
+      ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+      const float EPS = 1e-12f;
+      const float denom = sqrtf((ss + EPS) * (tt + EPS));
+      ca = -inj / denom;
+      cb = inj * st * (tt + EPS) / (denom * denom * denom);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
@@ -153,8 +176,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
         if (teacher && inj != 0.f) {
           // x = mu + xh / rstd (the row itself is no longer in registers)
           const float4 tv = rte[i];
-          o.x += inj * (mu + xh[i].x * istd - tv.x); o.y += inj * (mu + xh[i].y * istd - tv.y);
-          o.z += inj * (mu + xh[i].z * istd - tv.z); o.w += inj * (mu + xh[i].w * istd - tv.w);
+          const float4 xv = make_float4(mu + xh[i].x * istd, mu + xh[i].y * istd, mu + xh[i].z * istd, mu + xh[i].w * istd);
+          if (inj_cos) {
+            o.x += ca * tv.x + cb * xv.x; o.y += ca * tv.y + cb * xv.y; o.z += ca * tv.z + cb * xv.z; o.w += ca * tv.w + cb * xv.w;
+          } else {
+            o.x += inj * (xv.x - tv.x); o.y += inj * (xv.y - tv.y); o.z += inj * (xv.z - tv.z); o.w += inj * (xv.w - tv.w);
+          }
         }
         store4(dx + row * h + c, o);
         if (dx_lp) store4(dx_lp + row * h + c, o);

@@ -97,6 +97,10 @@ class GradReducer:
         self._avg = self._nccl if average == "auto" else bool(average)
         self.bytes_per_step = 0  # payload handed to the collectives in the last window (diagnostics / bench line)
         self.force = False       # tests: issue the collectives even with a single rank (a one-rank RCCL group on a one-GPU box)
+        # diagnostics (bench.py --gpus N): with ``time_wait`` every wait() brackets the compute stream's wait for the side stream with two
+        # timing events; exposed_wait_ms() = how long the compute stream stood still for the gradient exchange (0 = fully hidden)
+        self.time_wait = False
+        self._wait_events = []
         model.grad_ready_hook = self._on_ready
 
     def covered(self) -> int:
@@ -165,7 +169,15 @@ class GradReducer:
                     for w in works:
                         w.wait()
                     finish()
-            torch.cuda.current_stream().wait_stream(self._side)
+            cur = torch.cuda.current_stream()
+            if self.time_wait:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._side)
+                e1.record(cur)
+                self._wait_events.append((e0, e1))
+            else:
+                cur.wait_stream(self._side)
         else:
             for works, finish in self._works:
                 for w in works:
@@ -175,6 +187,16 @@ class GradReducer:
 
     def begin_window(self) -> None:
         self.bytes_per_step = 0
+
+    def exposed_wait_ms(self, reset: bool = True) -> List[float]:
+        """Per timed wait(): milliseconds the compute stream was blocked behind the bucket collectives (synchronises the device)."""
+        if not self._wait_events:
+            return []
+        torch.cuda.synchronize()
+        out = [float(e0.elapsed_time(e1)) for e0, e1 in self._wait_events]
+        if reset:
+            self._wait_events = []
+        return out
 
 
 def broadcast_teacher(model, src: int = 0, process_group=None) -> None:

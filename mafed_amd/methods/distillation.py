@@ -50,6 +50,22 @@ class _DistillSumsFn(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+def global_token_counts(sums: torch.Tensor, group=None) -> torch.Tensor:
+    """SURVEY.md section 8e, the optional exact normaliser: under data parallelism every rank divides its masked sums by ITS OWN
+    token counts (mafed/methods/distillation.py:248, distillation_loss_weights.py:148-155 see the local batch), so the gradient mean
+    over ranks weights ranks with fewer valid text tokens more.  Replacing {n_lang, n_vision} by their mean over ranks (one all-reduce
+    of two floats per layer row) makes  mean_ranks(loss_r)  equal the loss of ONE process holding the concatenated batch:
+    sum_r S_r / sum_r n_r.  Returns a new [nl, 4] tensor; identity without an initialised multi-rank group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return sums
+    out = sums.clone()
+    counts = out[:, 2:4].contiguous()
+    dist.all_reduce(counts, group=group)
+    out[:, 2:4] = counts / dist.get_world_size(group)
+    return out
+
+
 class _FusedDistillLossFn(torch.autograd.Function):
     """The whole MSE distillation term of the native model as ONE node: the per-layer masked sums (started layer by layer
     during the student forward, or computed here), then ``mafed_distill_combine`` -- masked means, modality weights, layer
@@ -61,7 +77,7 @@ class _FusedDistillLossFn(torch.autograd.Function):
     Outputs: (loss, per_layer [nl], modality [nl, 2]); only the loss is differentiable."""
 
     @staticmethod
-    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, early, coeffs, mode, lang_w, lang_vec, *student):
+    def forward(ctx, hook, attention_mask, P, teacher: Sequence[torch.Tensor], sv, layers, early, coeffs, mode, lang_w, lang_vec, cosine, exact_group, *student):
         nl = len(student)
         if early is not None:
             # the sums were started layer by layer during the student forward (FeatureDistillation._early_sums_hook)
@@ -70,9 +86,11 @@ class _FusedDistillLossFn(torch.autograd.Function):
         else:
             sums = torch.empty((nl, 4), dtype=torch.float32, device=student[0].device)
             for l in range(nl):
-                ops.distill_fwd(student[l], teacher[l], attention_mask, P, False, out=sums[l])
+                ops.distill_fwd(student[l], teacher[l], attention_mask, P, bool(cosine), out=sums[l])
+        if exact_group is not None:
+            sums = global_token_counts(sums, exact_group)
         loss, per_layer, modality, inject = ops.distill_combine(sums, coeffs, mode, lang_w, lang_vec)
-        ctx.sv, ctx.layers, ctx.teacher, ctx.inject = sv, list(layers), list(teacher), inject
+        ctx.sv, ctx.layers, ctx.teacher, ctx.inject, ctx.cosine = sv, list(layers), list(teacher), inject, bool(cosine)
         ctx.mark_non_differentiable(per_layer, modality)
         return loss.reshape(()), per_layer, modality
 
@@ -80,8 +98,9 @@ class _FusedDistillLossFn(torch.autograd.Function):
     def backward(ctx, g, _gp, _gm):
         scaled = ctx.inject * g  # [nl, 4] x upstream d / d loss (1 / accumulate_grad_batches under the Trainer)
         ctx.sv["inject"] = {layer: (ctx.teacher[k], scaled[k]) for k, layer in enumerate(ctx.layers)}
+        ctx.sv["inject_cosine"] = ctx.cosine
         ctx.sv = None
-        return (torch.zeros((), device=g.device),) + (None,) * (10 + len(ctx.layers))
+        return (torch.zeros((), device=g.device),) + (None,) * (12 + len(ctx.layers))
 
 
 class _DistillClsFn(torch.autograd.Function):
@@ -133,7 +152,10 @@ class FeatureDistillation(CLStrategy):
         self.num_vision_tokens = 256  # hard-coded upstream (distillation.py:73); instance attribute, settable
         self.mem_dataloader = None
         self.overlap_teacher = True
-        self.fused_distill = True  # MSE distillation gradient injected inside the model's LayerNorm-backward kernels
+        self.fused_distill = True  # distillation gradient (MSE or cosine) injected inside the model's LayerNorm-backward kernels
+        # data parallel only: masked means over the GLOBAL token counts (one small all-reduce per step; global_token_counts).  Off = the
+        # reference's per-rank means.  True = default process group, or pass a group.
+        self.exact_normaliser = kwargs.get("exact_normaliser", False)
         self._prefetched = None
         self.last_layer_losses: Optional[torch.Tensor] = None  # [n_layers] device tensor of the last distill() call
         self.last_modality_losses: Optional[torch.Tensor] = None  # [n_layers, 2] (lang, vision)
@@ -240,7 +262,7 @@ class FeatureDistillation(CLStrategy):
         them back to back after the forward -- they then run under the following layers' GEMMs."""
         self._early = None
         pre = getattr(self, "_prefetched", None)
-        if (not _EARLY_SUMS or pre is None or self._cosine or self._cls_distillation or not self.fused_distill or not self.overlap_teacher
+        if (not _EARLY_SUMS or pre is None or self._cls_distillation or not self.fused_distill or not self.overlap_teacher
                 or not hasattr(model, "hidden_ready_hook") or not torch.is_grad_enabled()):
             return False
         hs, ev, n = pre
@@ -255,6 +277,7 @@ class FeatureDistillation(CLStrategy):
         sums = torch.empty((len(layers), 4), dtype=torch.float32, device=dev)
         slot = {l: k for k, l in enumerate(layers)}
         state = {"sums": sums, "stream": side, "layers": layers, "n": len(layers)}
+        cosine = bool(self._cosine)
 
         def hook(l, x):
             k = slot.get(l)
@@ -263,7 +286,7 @@ class FeatureDistillation(CLStrategy):
             main = torch.cuda.current_stream()
             side.wait_event(main.record_event())   # hidden_states[l] is final on the caller's stream
             with torch.cuda.stream(side):           # (the teacher forward that produced hs[l] ran on this very stream)
-                ops.distill_fwd(x.view(B, P + T, -1), hs[l], am, P, False, out=sums[k])
+                ops.distill_fwd(x.view(B, P + T, -1), hs[l], am, P, cosine, out=sums[k])
 
         model.hidden_ready_hook = hook
         self._early = state
@@ -316,6 +339,16 @@ class FeatureDistillation(CLStrategy):
             hs = pm(**batch, output_hidden_states=True, return_dict=True).hidden_states
             return [x.detach() for x in hs]
 
+    def _exact_group(self):
+        """The process group of the exact-normaliser all-reduce (``exact_normaliser`` = True: the default group), or None."""
+        en = getattr(self, "exact_normaliser", False)
+        if not en:
+            return None
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return None
+        return dist.group.WORLD if en is True else en
+
     def distill(self, output, batch):
         layers = self.loss_weights.get_distillation_layers()
         past = self._get_past_hidden_states(batch, n_hidden=max(layers) + 1)
@@ -340,7 +373,7 @@ class FeatureDistillation(CLStrategy):
             students = [output.hidden_states[l] for l in layers]
             teachers = [past[l] for l in layers]
             mctx = getattr(output, "mafed_ctx", None)
-            if self.fused_distill and not self._cosine and mctx is not None:
+            if self.fused_distill and mctx is not None:
                 early = getattr(self, "_early", None)
                 self._early = None
                 if early is not None and (early["layers"] != list(layers) or early["n"] != len(layers)):
@@ -348,12 +381,15 @@ class FeatureDistillation(CLStrategy):
                 mode, lang_w, lang_vec = self.loss_weights.modality_mode(layers, dev)
                 loss, per_layer, modality = _FusedDistillLossFn.apply(
                     mctx[1], am, P, teachers, mctx[0], layers, (early["sums"], early["stream"].record_event()) if early is not None else None,
-                    coeffs, mode, lang_w, lang_vec, *students)
+                    coeffs, mode, lang_w, lang_vec, bool(self._cosine), self._exact_group(), *students)
                 self.last_modality_losses = modality
                 self.last_layer_losses = per_layer
                 self.step += 1
                 return loss
             sums = _DistillSumsFn.apply(am, P, self._cosine, teachers, *students)  # [nl, 4]
+            if self._exact_group() is not None:
+                counts = global_token_counts(sums.detach(), self._exact_group())[:, 2:4]
+                sums = torch.cat([sums[:, 0:2], counts], dim=1)
             lang = sums[:, 0] / sums[:, 2]
             vis = sums[:, 1] / sums[:, 3]
             lw, vw = self.loss_weights.modality_weight_vectors(sums[0, 2].detach(), sums[0, 3].detach(), layers, dev)

@@ -682,6 +682,7 @@ class VLPythiaForCausalLM(nn.Module):
         if len(dhidden) > L and dhidden[L] is not None:
             raise NotImplementedError("gradient w.r.t. the post-final-LayerNorm hidden state is not on the MAFED path")
         inject = sv.get("inject")  # {layer: (teacher hidden state, device [4] = d loss / d {sum_lang, sum_vision, ., .})}
+        inj_cos = bool(sv.get("inject_cosine", False))   # the injected loss is the cosine distance, not the MSE
         main = torch.cuda.current_stream()
         sides = self.side_streams() if self.overlap_param_grads else None
         keep: List[torch.Tensor] = []  # temporaries read by the side streams: kept alive until the join at the end
@@ -805,7 +806,7 @@ class VLPythiaForCausalLM(nn.Module):
                 # nothing flows into this layer's output (distillation of shallower layers only): its own backward is skipped,
                 # but a distilled hidden_states[i] (this layer's input) still starts the gradient for the layers below
                 if inj is not None:
-                    dx = ops.distill_bwd(sv["layers"][i]["x"].view(B, S, h), inj[0], am, P, inj[1]).view(rows, h)
+                    dx = ops.distill_bwd(sv["layers"][i]["x"].view(B, S, h), inj[0], am, P, inj[1], cosine=inj_cos).view(rows, h)
                     main_moved()
                 continue
             if dy is None:
@@ -832,7 +833,8 @@ class VLPythiaForCausalLM(nn.Module):
             dln1 = ops.gemm(dqkv, w(pre + "attention.query_key_value.weight"), False, False)
             # both LayerNorms + the residual path, one pass; also emits the compute-dtype copy the next layer's GEMMs read
             ln_kw = dict(want_lp=(cd != torch.float32), teacher=inj[0].view(rows, h) if inj is not None else None,
-                         attention_mask=am if inj is not None else None, S=S, P=P, inj_scale=inj[1] if inj is not None else None, inj_mul=2.0 / h)
+                         attention_mask=am if inj is not None else None, S=S, P=P, inj_scale=inj[1] if inj is not None else None,
+                         inj_mul=-1.0 if inj_cos else 2.0 / h)   # (a negative factor selects the cosine-distance gradient, mafed_hip.h)
             dxa = g(f"gpt_neox.layers.{i - 1}.mlp.dense_4h_to_h.bias") if i > 0 else None
             dxb = g(f"gpt_neox.layers.{i - 1}.attention.dense.bias") if i > 0 else None
             if defer_ln:

@@ -112,3 +112,67 @@ def test_reducer_rejects_unknown_modes():
         GradReducer(m, mode="ring")
     with pytest.raises(ValueError):
         GradReducer(m, grad_dtype=torch.float16)
+
+
+# ---- teacher broadcast, replay-memory rank shards, exact normaliser (CPU tensors over gloo) ------------------------------------
+def _aux_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mafed_amd.dist import broadcast_teacher
+        from mafed_amd.methods import HBMReplayBuffer
+        from mafed_amd.methods.distillation import global_token_counts
+        # (1) every replica's frozen teacher := rank 0's, and the bf16 shadow is marked stale
+        teacher = types.SimpleNamespace(flat_params=torch.full((1000,), float(rank + 1)), _shadow_dirty=False)
+        broadcast_teacher(teacher)
+        ok_bcast = bool((teacher.flat_params == 1.0).all()) and teacher._shadow_dirty
+        # (2) rank shards of the replay memory: every draw stays inside [n r / W, n (r + 1) / W)
+        n = 37
+        mem = HBMReplayBuffer(4, "cpu", seed=5 + rank, rank=rank, world_size=world)
+        mem.add({"input_ids": torch.arange(n).view(n, 1).repeat(1, 3), "attention_mask": torch.ones(n, 3, dtype=torch.int64),
+                 "labels": torch.full((n, 3), -100), "patch_embeddings": torch.zeros(n, 2, 4)})
+        seen = set()
+        for _ in range(200):
+            seen.update(int(i) for i in mem.sample()["input_ids"][:, 0])
+        # (3) exact normaliser: counts become the rank mean, sums stay local
+        sums = torch.tensor([[1.0 + rank, 2.0, 10.0 + 4 * rank, 64.0], [3.0, 4.0 + rank, 10.0 + 4 * rank, 64.0]])
+        gl = global_token_counts(sums)
+        q.put((rank, ok_bcast, sorted(seen), gl.tolist(), sums.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_teacher_broadcast_memory_shards_and_global_counts(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_aux_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+    n = 37
+    union = []
+    for rank, ok_bcast, seen, gl, sums in res:
+        assert ok_bcast, f"rank {rank}: teacher not equal to rank 0's after the broadcast"
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        assert seen == list(range(lo, hi)), f"rank {rank}: draws {seen[:3]}..{seen[-3:]} outside / not covering its shard [{lo}, {hi})"
+        union += seen
+        mean_lang = sum(10.0 + 4 * r for r in range(world)) / world
+        for row_g, row_s in zip(gl, sums):
+            assert row_g[:2] == row_s[:2] and row_g[2] == pytest.approx(mean_lang) and row_g[3] == 64.0
+    assert sorted(union) == list(range(n)), "the rank shards are disjoint and cover the memory"
+    # the point of the mean count: rank-mean of S_r / n_mean == sum S_r / sum n_r
+    S = [1.0 + r for r in range(world)]
+    N = [10.0 + 4 * r for r in range(world)]
+    nm = sum(N) / world
+    assert sum(s / nm for s in S) / world == pytest.approx(sum(S) / sum(N))
+
+
+def test_global_counts_are_the_identity_without_a_process_group():
+    from mafed_amd.methods.distillation import global_token_counts
+    s = torch.rand(3, 4)
+    assert global_token_counts(s) is s

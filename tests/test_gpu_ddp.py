@@ -188,3 +188,81 @@ def test_single_rank_rccl_collectives_are_the_identity(mode, grad_dtype):
     else:
         np.testing.assert_allclose(g_ddp, g_ref, rtol=1e-2)
         np.testing.assert_allclose(p_ddp, p_ref, rtol=0, atol=2.5e-3)
+
+
+def _exact_worker(rank, world, port, q, exact, modality):
+    import torch.distributed as dist
+    from mafed_amd import FeatureDistillation
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = tiny_cfg("m64")
+        sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
+        tsd = R.perturb(sd, seed=22, std=5e-3)
+        model, teacher = _build(cfg, sd), _build(cfg, tsd)
+        fd = _exact_fd(cfg, teacher, modality, exact)
+        fd.mem_dataloader = [_exact_batch(cfg, rank)]
+        loss, _ = fd.replay(model)
+        loss.backward()
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), model.flat_grads.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _exact_fd(cfg, teacher, modality, exact):
+    from mafed_amd import FeatureDistillation
+    t = TINY["m64"]
+    opts = types.SimpleNamespace(tasks=["a", "b"], batch_size=t["B"], seed=3, pin_mem=False, accumulate_grad_batches=1)
+    fd = FeatureDistillation(memory_size=10, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                             distillation_modality_weighing_strategy=modality, distillation_layer_weighing_strategy="discounted",
+                             gamma=0.5, distillation_layer=None, replay_coeff=0.0, exact_normaliser=exact)
+    fd._update_model(teacher)
+    fd.task_id = 1
+    fd.num_vision_tokens = cfg.num_vision_tokens
+    return fd
+
+
+def _exact_batch(cfg, rank):
+    t = TINY["m64"]
+    b = R.make_batch(cfg, t["B"], t["T"], seed=300 + rank, pad=True, n_answer=3)
+    if rank == 1:   # make the ranks' valid-text-token counts clearly different
+        b["attention_mask"][:, : t["T"] // 2] = 0
+        b["input_ids"][:, : t["T"] // 2] = 0
+    return {k: v.cuda() for k, v in b.items()}
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("modality", ["balanced", "equal"])
+def test_exact_normaliser_equals_one_process_with_the_concatenated_batch(modality):
+    """with ``exact_normaliser`` the rank MEAN of the distillation losses / gradients is the loss / gradient of one
+    process holding both ranks' batches (masked means over the global token counts); without it (the reference's behaviour:
+    distillation.py:248 normalises by the local counts) it is not, when the ranks' pad counts differ."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = {}
+    for exact in (True, False):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_exact_worker, args=(r, world, port, q, exact, modality)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=400) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(30)
+        out[exact] = (np.mean([r[1] for r in res]), np.mean([r[2] for r in res], axis=0))
+    cfg = tiny_cfg("m64")
+    sd = R.init_weights(cfg, seed=21, bias_std=0.02, ln_jitter=0.05)
+    tsd = R.perturb(sd, seed=22, std=5e-3)
+    model, teacher = _build(cfg, sd), _build(cfg, tsd)
+    fd = _exact_fd(cfg, teacher, modality, False)
+    b0, b1 = _exact_batch(cfg, 0), _exact_batch(cfg, 1)
+    fd.mem_dataloader = [{k: torch.cat([b0[k], b1[k]], dim=0) for k in b0}]
+    loss, _ = fd.replay(model)
+    loss.backward()
+    ref_loss, ref_grad = float(loss), model.flat_grads.detach().cpu().numpy()
+    scale = np.abs(ref_grad).max()
+    assert abs(out[True][0] - ref_loss) <= 1e-5 * abs(ref_loss)
+    np.testing.assert_allclose(out[True][1], ref_grad, rtol=0, atol=2e-5 * scale)
+    assert abs(out[False][0] - ref_loss) > 1e-3 * abs(ref_loss), "the test batches must make the local and the global normaliser differ"

@@ -298,6 +298,41 @@ def test_layernorm_bwd_many_rows_and_injection():
     assert_close(db2, dy2.double().sum(0), 1e-4, "db2")
 
 
+def test_layernorm_bwd_cosine_injection():
+    """inj_mul < 0: the fused injection adds scale[class] * d/dx (1 - cos(x, teacher)) (mafed_distill_fwd's epsilon) per row."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    B, P, T, h = 5, 20, 12, 192
+    S = P + T
+    rows = B * S
+    x = torch.randn(rows, h, generator=g)
+    t = x + 0.5 * torch.randn(rows, h, generator=g)
+    w1 = torch.randn(h, generator=g)
+    dy1 = torch.randn(rows, h, generator=g)
+    am = torch.ones(B, T, dtype=torch.int64)
+    for b in range(B):
+        am[b, : (b * 5) % T] = 0
+    scales = torch.tensor([0.9, -0.4])
+    xd = x.double().requires_grad_(True)
+    z = torch.zeros(h, dtype=torch.float64)
+    lang, img = R.modality_masks(am, P)
+    rw = scales[0] * lang.reshape(-1).double() + scales[1] * img.reshape(-1).double()
+    td = t.double()
+    dist = 1.0 - (xd * td).sum(-1) / torch.sqrt(((xd * xd).sum(-1) + 1e-12) * ((td * td).sum(-1) + 1e-12))
+    tot = (F.layer_norm(xd, (h,), w1.double(), z, 1e-5) * dy1.double()).sum() + (rw * dist).sum()
+    tot.backward()
+    D = lambda v: v.to(DEV)
+    _, _, mean, rstd = ops.layernorm_fwd(D(x), D(w1), D(z.float()), None, None, 1e-5, torch.float32)
+    dw1, db1 = torch.zeros(h, device=DEV), torch.zeros(h, device=DEV)
+    dx, _ = ops.layernorm_bwd(D(dy1), None, D(x), mean, rstd, D(w1), None, None, dw1, db1, None, None,
+                              teacher=D(t), attention_mask=D(am), S=S, P=P, inj_scale=D(scales), inj_mul=-1.0)
+    assert_close(dx, xd.grad, 1e-4, "dx + cosine injection")
+    # the same through the stand-alone kernel (what the generic path materialises)
+    ds = ops.distill_bwd(D(x).view(B, S, h), D(t).view(B, S, h), D(am), P, D(scales), True)
+    dx0, _ = ops.layernorm_bwd(D(dy1), None, D(x), mean, rstd, D(w1), None, None, dw1, db1, None, None)
+    assert_close(dx, dx0 + ds.view(rows, h), 1e-5, "fused = LayerNorm backward + distill_bwd")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------------------------

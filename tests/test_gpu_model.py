@@ -127,18 +127,27 @@ def test_mafed_replay_vs_reference_golden(name, vname):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("replay_coeff", [0.7, 0.0])
-def test_mafed_fused_and_generic_distillation_paths(fused, replay_coeff):
-    """MSE distillation gradient injected inside the LayerNorm-backward kernels (fused) vs materialised per layer through
-    plain autograd (generic; what the reference's own plugin code would exercise), with and without the replay CE term."""
+@pytest.mark.parametrize("vname", ["equal_discounted_g09_mse", "balanced_discounted_g05_cosine"])
+def test_mafed_fused_and_generic_distillation_paths(fused, replay_coeff, vname, monkeypatch):
+    """Distillation gradient (MSE, and the cosine distance of distillation.py:226-235) injected inside the LayerNorm-backward
+    kernels (fused) vs materialised per layer through plain autograd (generic; what the reference's own plugin code would
+    exercise), with and without the replay CE term.  The fused path must not materialise a per-layer gradient tensor."""
+    from mafed_amd import ops
     cfg, sd, tsd, batch, g = golden_setup("m64")
     model, teacher = build_model(cfg, sd), build_model(cfg, tsd)
-    fd, spec = make_fd(cfg, "equal_discounted_g09_mse", g, teacher, batch, batch["input_ids"].shape[0])
+    fd, spec = make_fd(cfg, vname, g, teacher, batch, batch["input_ids"].shape[0])
     fd.replay_coeff = replay_coeff
     fd.fused_distill = fused
     fd.mem_dataloader = [to_dev(batch)]
+    calls = []
+    real = ops.distill_bwd
+    monkeypatch.setattr(ops, "distill_bwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     model.zero_grad()
     loss, _ = fd.replay(model)
     loss.backward()
+    n_distilled = len(fd.loss_weights.get_distillation_layers())
+    # (with no CE term the deepest distilled state starts the gradient chain: that one row tensor is the chain's seed, not an extra pass)
+    assert len(calls) == ((1 if replay_coeff == 0.0 else 0) if fused else n_distilled), (fused, len(calls))
     spec.replay_coeff = replay_coeff
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref_loss, _, _ = R.mafed_replay_loss(params, tsd, batch, cfg, spec, task_id=1)
