@@ -1,6 +1,4 @@
-mkdir -p gpurun_out/r3i
-timeout -k 10 300 python -m pytest tests/test_gpu_gemm_pp.py -m gpu -x -q > gpurun_out/r3i/pp_tests.log 2>&1 || exit 1
-for lib in lib_pd3 libmafed_hip lib_pd12 lib_pd3 libmafed_hip lib_pd12; do
-    echo "== $lib" >> gpurun_out/r3i/pd.log
-    MAFED_HIP_LIB=$PWD/mafed_amd/$lib.so GEMM_BENCH_EPI=1 GEMM_BENCH_ONLY=fc1,fc2,dfc2,qkv timeout -k 10 120 python tools/gemm_bench.py 700,701 >> gpurun_out/r3i/pd.log 2>&1 || exit 1
-done
+mkdir -p gpurun_out/r3j
+timeout -k 10 900 python -m pytest tests/test_gpu_ddp.py -m gpu -x -q > gpurun_out/r3j/tests.log 2>&1 || exit 1
+MAFED_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-secondary --no-image-leg --no-kernel-profile --exact-normaliser --memory-size 1000 > gpurun_out/r3j/bench2.json 2> gpurun_out/r3j/bench2.err || exit 1
+timeout -k 10 300 python bench.py --no-secondary --no-image-leg --no-cpu-baseline > gpurun_out/r3j/bench1.json 2> gpurun_out/r3j/bench1.err
