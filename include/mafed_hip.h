@@ -267,6 +267,13 @@ int mafed_adamw_step_zero_grad(float* p, float* g, float* m, float* v, int64_t n
 int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1, double beta2,
                         float* hyper3_dev, void* stream);
 
+/* mafed_gradnorm_finish followed by mafed_optim_advance as ONE launch (both are single-thread tails on the optimiser step's critical
+ * path); norm_log (or NULL) additionally receives the norm -- a slot the caller owns, e.g. for the step's log record, so that no
+ * device copy of out2[0] is needed before the next step overwrites it.  Same arithmetic, bit for bit, as the two calls. */
+int mafed_gradnorm_finish_advance(const float* partial, int n_partials, float max_norm, float* out2, float* norm_log, int64_t* state_dev,
+                                  double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1, double beta2, float* hyper3_dev,
+                                  void* stream);
+
 /* ---- small utilities --------------------------------------------------------------------------------------------- */
 int mafed_cast(const void* src, mafed_dtype src_dtype, void* dst, mafed_dtype dst_dtype, int64_t n, void* stream);
 /* dst [B,S,h] fp32 = zeros for the P image positions of every sample, src [B,S-P,h] for its text positions; dst_lp (bf16, optional): the

@@ -100,9 +100,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 
 // One thread: advance the optimiser step counter and publish this step's scalars {lr, 1-b1^t, sqrt(1-b2^t)} in double
 // precision, so that a whole training step (schedule included) replays from a hipGraph without host involvement.
-__global__ void optim_advance_kernel(long long* __restrict__ state, double base_lr, long long warmup, long long total, double b1,
-                                     double b2, float* __restrict__ hyper) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void optim_advance_body(long long* __restrict__ state, double base_lr, long long warmup, long long total, double b1,
+                                                   double b2, float* __restrict__ hyper) {
   const long long t = state[0] + 1;
   state[0] = t;
   const long long s = t - 1;  // LambdaLR epoch in force during optimiser step t (scheduler steps once per optimiser step)
@@ -118,6 +117,40 @@ __global__ void optim_advance_kernel(long long* __restrict__ state, double base_
   hyper[0] = (float)(base_lr * lam);
   hyper[1] = (float)(1.0 - pow(b1, (double)t));
   hyper[2] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+
+__global__ void optim_advance_kernel(long long* __restrict__ state, double base_lr, long long warmup, long long total, double b1,
+                                     double b2, float* __restrict__ hyper) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  optim_advance_body(state, base_lr, warmup, total, b1, b2, hyper);
+}
+
+// gradnorm_finish_kernel + optim_advance_kernel as ONE launch (the two sat back to back, with a 4-byte device copy of the norm for the
+// step's log between them, on the optimiser step's critical path): also leaves the norm in `norm_log` (a slot the caller owns).
+__global__ __launch_bounds__(256) void gradnorm_finish_advance_kernel(const float* __restrict__ partial, int nblk, float max_norm,
+                                                                      float* __restrict__ out2, float* __restrict__ norm_log,
+                                                                      long long* __restrict__ state, double base_lr, long long warmup,
+                                                                      long long total, double b1, double b2, float* __restrict__ hyper) {
+  __shared__ float sm[4];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = threadIdx.x;
+  for (; b + 7 * 256 < nblk; b += 8 * 256) {   // (same association as gradnorm_finish_kernel: bit-identical norm)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[b + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += v[u];
+  }
+  for (; b < nblk; b += 256) acc[0] += partial[b];
+  float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  s = block_sum<256>(s, sm);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(s);
+    out2[0] = norm;
+    out2[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+    if (norm_log) norm_log[0] = norm;
+    optim_advance_body(state, base_lr, warmup, total, b1, b2, hyper);
+  }
 }
 
 }  // namespace mafed
@@ -177,6 +210,16 @@ extern "C" int mafed_gradnorm_finish(const float* partial, int n_partials, float
   MAFED_CHECK_ARG(partial && out2 && n_partials >= 1, "gradnorm_finish: bad arguments");
   launch(K_SMALL, 0.0, gradnorm_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, n_partials, max_norm, out2);
   MAFED_CHECK_LAUNCH("gradnorm_finish");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_gradnorm_finish_advance(const float* partial, int n_partials, float max_norm, float* out2, float* norm_log,
+                                             int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1,
+                                             double beta2, float* hyper3_dev, void* stream) {
+  MAFED_CHECK_ARG(partial && out2 && n_partials >= 1 && state_dev && hyper3_dev, "gradnorm_finish_advance: bad arguments");
+  launch(K_SMALL, 0.0, gradnorm_finish_advance_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, n_partials, max_norm, out2, norm_log,
+         (long long*)state_dev, base_lr, (long long)warmup_steps, (long long)total_steps, beta1, beta2, hyper3_dev);
+  MAFED_CHECK_LAUNCH("gradnorm_finish_advance");
   return MAFED_OK;
 }
 

@@ -100,7 +100,8 @@ class _FusedDistillLossFn(torch.autograd.Function):
         ctx.sv["inject"] = {layer: (ctx.teacher[k], scaled[k]) for k, layer in enumerate(ctx.layers)}
         ctx.sv["inject_cosine"] = ctx.cosine
         ctx.sv = None
-        return (torch.zeros((), device=g.device),) + (None,) * (12 + len(ctx.layers))
+        # (the hook's "gradient" only makes the model's node run; its value is never read: no fill kernel for it)
+        return (torch.empty((), device=g.device),) + (None,) * (12 + len(ctx.layers))
 
 
 class _DistillClsFn(torch.autograd.Function):

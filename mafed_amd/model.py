@@ -959,11 +959,13 @@ class _ModelFn(torch.autograd.Function):
         ctx.model, ctx.sv = model, sv
         ctx_box.append(sv)
         ctx.set_materialize_grads(False)  # outputs nobody differentiated arrive as None, not as zero tensors
-        loss = sv["loss"].reshape(()).clone() if sv["loss"] is not None else torch.zeros((), device=anchor.device)
+        # (a 0-dim view of the CE kernel's own output: a clone here was a device copy on the chain between forward and backward)
+        loss = sv["loss"].reshape(()) if sv["loss"] is not None else torch.zeros((), device=anchor.device)
         # outs[2] is a 0-dim "hook": the fused distillation node takes it as an input so that this node's backward runs
-        # (after the distillation node has left its per-layer coefficients in sv["inject"]) even without a CE gradient
+        # (after the distillation node has left its per-layer coefficients in sv["inject"]) even without a CE gradient; nobody reads
+        # its value, so it is not filled
         pub = sv["logits"] if sv.get("sparse_head") is None else torch.empty(0, device=anchor.device)   # compact logits are internal
-        outs = [loss, pub.detach(), torch.zeros((), device=anchor.device)]
+        outs = [loss, pub.detach(), torch.empty((), device=anchor.device)]
         ctx.mark_non_differentiable(outs[1])
         if want_hidden:
             outs += [x.detach() for x in sv["hidden"]]  # aliases: no reference cycle through ctx

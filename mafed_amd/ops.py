@@ -444,16 +444,20 @@ def gradnorm_partial(g: torch.Tensor, partial_out: torch.Tensor) -> None:
     check(_lib.load().mafed_gradnorm_partial(_ptr(g), g.numel(), _ptr(partial_out), _stream()), "mafed_gradnorm_partial")
 
 
-def gradnorm_finish(partials: torch.Tensor, max_norm: float, out2: torch.Tensor) -> torch.Tensor:
-    check(_lib.load().mafed_gradnorm_finish(_ptr(partials), partials.numel(), float(max_norm), _ptr(out2), _stream()), "mafed_gradnorm_finish")
+def gradnorm_finish(partials: torch.Tensor, max_norm: float, out2: torch.Tensor, advance=None, norm_log: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fold the per-range partials into out2 = {norm, clip scale}.  ``advance`` = (state, base_lr, warmup, total, beta1, beta2, hyper):
+    the optimiser's schedule advance rides in the same launch (mafed_gradnorm_finish_advance); ``norm_log`` = a 1-element slot that
+    also receives the norm."""
+    if advance is None:
+        check(_lib.load().mafed_gradnorm_finish(_ptr(partials), partials.numel(), float(max_norm), _ptr(out2), _stream()), "mafed_gradnorm_finish")
+        if norm_log is not None:
+            norm_log.copy_(out2[0:1])
+    else:
+        state, base_lr, warmup, total, b1, b2, hyper = advance
+        check(_lib.load().mafed_gradnorm_finish_advance(_ptr(partials), partials.numel(), float(max_norm), _ptr(out2), _ptr(norm_log), _ptr(state),
+                                                        float(base_lr), int(warmup), int(total), float(b1), float(b2), _ptr(hyper), _stream()),
+              "mafed_gradnorm_finish_advance")
     return out2
-
-
-def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None, zero_grad: bool = False) -> None:
-    """``zero_grad``: the kernel also writes zeros over ``g`` (the next window's optimizer.zero_grad(), same pass)."""
-    fn = _lib.load().mafed_adamw_step_zero_grad if zero_grad else _lib.load().mafed_adamw_step
-    check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
-             int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
 
 
 def optim_advance_(state: torch.Tensor, base_lr: float, warmup: int, total: int, beta1: float, beta2: float, hyper: torch.Tensor) -> None:

@@ -73,7 +73,11 @@ class FlatAdamW:
         self._sched = (int(warmup_steps), int(total_steps))
 
     def advance(self) -> None:
-        """First kernel of an optimiser step (capturable): t += 1 and {lr(t-1), 1-b1^t, sqrt(1-b2^t)} -> lr_dev."""
+        """First kernel of an optimiser step (capturable): t += 1 and {lr(t-1), 1-b1^t, sqrt(1-b2^t)} -> lr_dev.  A no-op when
+        clip_grad_norm_(fuse_advance=True) has already done it for this step inside the norm's finish launch."""
+        if getattr(self, "_advanced", False):
+            self._advanced = False
+            return
         ops.optim_advance_(self.state_dev, self.base_lr, self._sched[0], self._sched[1], self.betas[0], self.betas[1], self.lr_dev)
 
     def host_advance(self) -> None:
@@ -131,15 +135,32 @@ class FlatAdamW:
         hook.is_norm_hook = True   # Trainer replaces / removes hooks of this kind only
         return hook
 
-    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+    NORM_LOG_SLOTS = 4096
+
+    def clip_grad_norm_(self, max_norm: float, fuse_advance: bool = False) -> torch.Tensor:
         """Global L2 norm + clip scale on the device; the scale is applied inside the AdamW kernel.  Uses the partials left by the
-        backward's hooks when every range reported in this backward, the single pass otherwise."""
+        backward's hooks when every range reported in this backward, the single pass otherwise.
+        ``fuse_advance`` (Trainer): with the partials present, the schedule advance of this optimiser step runs in the finish launch
+        (advance() then does nothing) and the returned norm is a view of a log slot of its own -- valid until NORM_LOG_SLOTS further
+        optimiser steps have run -- instead of ``clip_out[0]``, which the next step overwrites (callers clone that one)."""
         plan = getattr(self, "_norm_plan_cache", None)
         seen = getattr(self, "_norm_seen", None)
         last = getattr(self.model, "_bw_serial", 0)
         # complete = every range reported during the LAST backward sweep (a sweep that skipped layers, or a plugin's extra sweep
         # before it, leaves older partials behind: then the buffer is read in one pass as before)
         if plan is not None and seen is not None and len(seen) == len(plan) and all(v == last for v in seen.values()):
+            if fuse_advance:
+                if not hasattr(self, "_norm_log"):
+                    self._norm_log = torch.zeros(self.NORM_LOG_SLOTS, dtype=torch.float32, device=self.clip_out.device)
+                    self._norm_log_i = 0
+                slot = self._norm_log[self._norm_log_i % self.NORM_LOG_SLOTS: self._norm_log_i % self.NORM_LOG_SLOTS + 1]
+                self._norm_log_i += 1
+                ops.gradnorm_finish(self._norm_partials, max_norm, self.clip_out, norm_log=slot,
+                                    advance=(self.state_dev, self.base_lr, self._sched[0], self._sched[1], self.betas[0], self.betas[1], self.lr_dev))
+                self._advanced = True
+                self._norm_seen = None
+                self._clip_pending = True
+                return slot[0]
             ops.gradnorm_finish(self._norm_partials, max_norm, self.clip_out)
         else:
             ops.gradnorm_clip(self.model.flat_grads, max_norm, self.clip_out)

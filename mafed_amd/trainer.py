@@ -56,6 +56,7 @@ class Trainer:
         # DDP the gradient hook belongs to the reducer; plugins that touch gradients outside the model's backward keep the one-pass norm)
         self.incremental_norm = bool(incremental_norm)
         self.global_step = 0
+        self._one = None
         self.optimizer.zero_grad()
         self.on_train_start()
 
@@ -101,7 +102,10 @@ class Trainer:
             else:
                 self.optimizer._norm_seen = None
         loss, branch = self._training_step(batch, is_replay)
-        (loss / self.accumulate if self.accumulate != 1 else loss).backward()
+        # (an explicit root gradient: autograd's implicit ones_like is a fill kernel per step on the chain between forward and backward)
+        if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+            self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        (loss / self.accumulate if self.accumulate != 1 else loss).backward(gradient=self._one)
         if torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
             # lets the next step's frozen-teacher forward start here, under this step's clip + AdamW
             # (the model's own event marks the end of the dX chain: the teacher forward then starts under the parameter-gradient tail)
@@ -115,7 +119,9 @@ class Trainer:
             if self.reducer is not None:
                 self.reducer.wait()
             if self.grad_norm and self.grad_norm > 0:
-                rec["grad_norm"] = self.optimizer.clip_grad_norm_(self.grad_norm).clone()
+                gn = self.optimizer.clip_grad_norm_(self.grad_norm, fuse_advance=True)
+                # (fused finish + advance leaves the norm in a log slot of its own; the one-pass form returns clip_out[0], overwritten next step)
+                rec["grad_norm"] = gn if getattr(self.optimizer, "_advanced", False) else gn.clone()
             self.optimizer.advance()
             if self.pipeline_optimizer:
                 self.model._param_events = self.optimizer.apply_pipelined(self._opt_stream)

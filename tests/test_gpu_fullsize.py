@@ -181,3 +181,72 @@ def test_left_padding_is_invisible_at_valid_positions():
     # its text rows differ only through the rotary position (k later): same tokens, same causal context => close, not equal
     assert b.logits.shape == a.logits.shape
     assert torch.isfinite(b.logits).all()
+
+
+def test_configs4_step_fed_by_the_resident_replay_memory():
+    """BASELINE.json configs[4] on one GPU: VLPythia-1.4B + MAFED with the experience-replay memory (4000 samples, bf16 patch features
+    resident in HBM, gathered one draw ahead on the loader stream) feeding Trainer.step().  The buffer's draws are a seeded permutation:
+    the same steps fed with hand-gathered batches of the same indices give the same losses and parameters bit for bit (the prefetch
+    stream, its events and the attached label-row hint change nothing), and distinct steps see distinct batches."""
+    from mafed_amd import Trainer
+    from mafed_amd.methods import HBMReplayBuffer
+    n_mem, seed, steps = 4000, 77, 3
+
+    def samples(cfg):
+        ids = torch.randint(1, cfg.vocab_size, (n_mem, T), generator=torch.Generator().manual_seed(5))
+        labels = torch.full((n_mem, T), -100, dtype=torch.int64)
+        labels[:, -4:] = ids[:, -4:]
+        feats = torch.empty(n_mem, P, cfg.vision_hidden_size, dtype=torch.bfloat16, device=DEV)
+        gd = torch.Generator(device=DEV).manual_seed(6)
+        for lo in range(0, n_mem, 500):
+            feats[lo:lo + 500] = torch.randn(500, P, cfg.vision_hidden_size, generator=gd, device=DEV).to(torch.bfloat16)
+        return {"input_ids": ids, "attention_mask": torch.ones(n_mem, T, dtype=torch.int64), "labels": labels, "patch_embeddings": feats}
+
+    def run(use_buffer):
+        cfg, student, fd = _setup(preset="1.4b")
+        data = samples(cfg)
+        conf = types.SimpleNamespace(accumulate_grad_batches=1, replay_interval=1, grad_norm=2.0, learning_rate=1e-4, betas=(0.9, 0.98),
+                                     weight_decay=0.01, optim="adamw", warmup_steps=0, total_steps=100)
+        mem = HBMReplayBuffer(B, DEV, seed=seed)
+        mem.add(data)
+        assert len(mem) == n_mem and mem.max_label_rows == 4
+        resident = sum(v.numel() * v.element_size() for v in mem.data.values())
+        assert resident >= n_mem * P * cfg.vision_hidden_size * 2
+        if use_buffer:
+            fd.mem_dataloader = mem
+        else:
+            gen = torch.Generator().manual_seed(seed)
+            idxs = [torch.randperm(n_mem, generator=gen)[:B] for _ in range(steps + 1)]   # (+1: the buffer gathers one draw ahead)
+            batches = []
+            for ix in idxs:
+                b = {k: v.to(DEV).index_select(0, ix.to(DEV)) for k, v in data.items()}
+                b["max_label_rows"] = 4
+                batches.append(b)
+            it = iter(batches)
+
+            class Feed:
+                def __iter__(self):
+                    return self
+                def __next__(self):
+                    return dict(next(it))
+            fd.mem_dataloader = Feed()
+        tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=100, pipeline_optimizer=True)
+        task = {k: v[:B].to(DEV) for k, v in data.items()}
+        losses = []
+        for i in range(steps):
+            rec = tr.step(task, i)
+            losses.append(float(rec["loss"]))
+        tr.join()
+        torch.cuda.synchronize()
+        chk = float(student.flat_params.double().sum())
+        del tr, student, fd, mem
+        return losses, chk
+
+    la, ca = run(True)
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    lb, cb = run(False)
+    assert all(l == l and l < 20.0 for l in la), la
+    assert len(set(la)) == steps, "every step drew a different batch"
+    assert la == lb, (la, lb)
+    assert ca == cb
