@@ -460,6 +460,13 @@ def gradnorm_finish(partials: torch.Tensor, max_norm: float, out2: torch.Tensor,
     return out2
 
 
+def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None, zero_grad: bool = False) -> None:
+    """``zero_grad``: the kernel also writes zeros over ``g`` (the next window's optimizer.zero_grad(), same pass)."""
+    fn = _lib.load().mafed_adamw_step_zero_grad if zero_grad else _lib.load().mafed_adamw_step
+    check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
+             int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
+
+
 def optim_advance_(state: torch.Tensor, base_lr: float, warmup: int, total: int, beta1: float, beta2: float, hyper: torch.Tensor) -> None:
     check(_lib.load().mafed_optim_advance(_ptr(state), float(base_lr), int(warmup), int(total), float(beta1), float(beta2),
                                           _ptr(hyper), _stream()), "mafed_optim_advance")

@@ -248,3 +248,20 @@ def test_clip_tower_row_padding_minimises_tile_rounds():
     for rows in (1, 100, 257, 5000):
         p = _pad_rows(rows, (1024, 3072, 4096))
         assert p >= rows and (p % 128 == 0 or p % 144 == 0)
+
+
+def test_every_ops_attribute_the_package_uses_exists():
+    """The host code reaches the kernels through ``mafed_amd.ops``; a wrapper lost in an edit only shows on the GPU box otherwise."""
+    import glob
+    import os
+    import re
+    from mafed_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "mafed_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(root, "tests", "*.py")) + \
+        glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    missing = set()
+    for f in files:
+        for m in re.finditer(r"\bops\.([A-Za-z_][A-Za-z_0-9]*)", open(f).read()):
+            if not hasattr(ops, m.group(1)):
+                missing.add((os.path.basename(f), m.group(1)))
+    assert not missing, missing
