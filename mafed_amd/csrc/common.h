@@ -137,37 +137,31 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-// Fast erf-GELU for the bf16 MFMA epilogues (Abramowitz-Stegun 7.1.26, |err(erf)| <= 1.5e-7; one v_exp + one v_rcp per
-// element): the libm erff costs more VALU time than the MFMA main loop leaves idle.  exp(-z^2) with z = x/sqrt(2) is also
-// the Gaussian of gelu', so the derivative needs no second exponential.  Written on float2 so that the polynomial, the
-// scalings and the final combination compile to packed v_pk_{mul,add,fma}_f32 (two elements per instruction); only the
-// two transcendentals and the sign handling stay per element.  The fp32 parity path keeps erff.
-__device__ __forceinline__ void erf_gauss_fast2(f32x2 x, f32x2& erf_z, f32x2& gauss) {
-  f32x2 ax;
-  ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
-  const f32x2 z = ax * 0.70710678118654752440f;
-  const f32x2 den = z * 0.3275911f + 1.0f;
-  f32x2 t;
-  t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);  // v_rcp_f32 (1 ulp): __frcp_rn expands to the ~10-instruction correctly rounded division
-  const f32x2 a = z * z * -1.4426950408889634f;  // exp(-z^2) = exp2(-z^2 * log2 e)
-  gauss[0] = __builtin_amdgcn_exp2f(a[0]); gauss[1] = __builtin_amdgcn_exp2f(a[1]);
-  f32x2 p = t * 1.061405429f + -1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t + -0.284496736f;
-  p = p * t + 0.254829592f;
-  const f32x2 e = 1.0f - p * t * gauss;
-  erf_z[0] = copysignf(e[0], x[0]); erf_z[1] = copysignf(e[1], x[1]);
+// Fast erf-GELU for the bf16 MFMA epilogues: Phi(x) - 1/2 = x P(s) and gelu'(x) - 1/2 = x Q(s) (both odd), x clamped to [-R, R],
+// s = 2 x^2 / R^2 - 1, P / Q = Chebyshev interpolants in monomial form (tools/gelu_poly_fit.py prints the arrays and their errors:
+// |Phi err| <= 2.3e-6, |gelu err| <= 1.8e-5, |gelu' err| <= 1.2e-5 over [-8, 8] in fp32 Horner -- below the bf16 rounding of the
+// stored activation / gradient everywhere).  Everything is packed v_pk_{mul,fma}_f32 on element pairs plus one v_med3 per element for the
+// clamp: ~60 issue cycles per pair, no transcendental.  The Abramowitz-Stegun form used until round 2 (one v_rcp + one v_exp per element,
+// both quarter rate) cost ~140 and made the GELU epilogues VALU-bound: 22.8 us of the 4h up-projection's 99.8 (11 k cycles per tile
+// against a 29 k-cycle K loop).  The fp32 parity path keeps erff.
+constexpr float GELU_P_R = 4.5f, GELU_Q_R = 5.0f;
+constexpr float GELU_P[11] = {1.569049965e-01f, -7.719375885e-02f, 5.469785678e-02f, -4.011058319e-02f, 2.831077579e-02f, -1.901597806e-02f,
+                              1.136370917e-02f, -5.258188585e-03f, 2.802886231e-03f, -2.337056659e-03f, 9.459542584e-04f};
+constexpr float GELU_Q[13] = {1.421339443e-01f, -7.509349723e-02f, 6.655416207e-02f, -7.222797948e-02f, 8.061209880e-02f, -8.095120240e-02f,
+                              7.859707870e-02f, -7.980066804e-02f, 5.597591266e-02f, -1.508289572e-02f, 1.306347472e-02f, -2.578379958e-02f,
+                              1.200570532e-02f};
+template <int N>
+__device__ __forceinline__ f32x2 gelu_odd_poly2(f32x2 x, const float (&c)[N], float R) {   // -> 1/2 + xc * poly(s), xc = clamp(x, -R, R)
+  f32x2 xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -R, R); xc[1] = __builtin_amdgcn_fmed3f(x[1], -R, R);
+  const f32x2 s = xc * xc * (2.0f / (R * R)) + -1.0f;
+  f32x2 r = s * c[N - 1] + c[N - 2];
+#pragma unroll
+  for (int i = N - 3; i >= 0; --i) r = r * s + c[i];
+  return xc * r + 0.5f;
 }
-__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
-  f32x2 e, g;
-  erf_gauss_fast2(x, e, g);
-  return x * 0.5f * (e + 1.0f);
-}
-__device__ __forceinline__ f32x2 gelu_erf_grad_fast2(f32x2 x) {
-  f32x2 e, g;
-  erf_gauss_fast2(x, e, g);
-  return (e + 1.0f) * 0.5f + x * 0.39894228040143267794f * g;
-}
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) { return x * gelu_odd_poly2(x, GELU_P, GELU_P_R); }
+__device__ __forceinline__ f32x2 gelu_erf_grad_fast2(f32x2 x) { return gelu_odd_poly2(x, GELU_Q, GELU_Q_R); }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   f32x2 v = {x, x};
   return gelu_erf_fast2(v)[0];

@@ -676,7 +676,7 @@ extern "C" int mafed_gemm_colsum(mafed_dtype in_dtype, int transA, int transB, i
 // (16-byte row segments: every pointer 16-byte aligned, ldc a multiple of 8; fused column sums only in its prefetching epilogues).
 static bool pp_fill_problem(PPProblem& pr, bool a_ks, bool b_ks, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                             int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const GemmEpi& epi, float* colsum) {
-  (void)a_ks; (void)b_ks; (void)M; (void)N; (void)K;
+  (void)M; (void)N; (void)K;
   const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)epi.aux | (uintptr_t)epi.res1 | (uintptr_t)epi.res2 |
                        (uintptr_t)epi.bias | (uintptr_t)colsum;
   if ((al & 15) || ldc % 8 || lda % 8 || ldb % 8) return false;
@@ -685,6 +685,8 @@ static bool pp_fill_problem(PPProblem& pr, bool a_ks, bool b_ks, int64_t M, int6
                     (pair && epi.mode == MAFED_EPI_GELU_BWD && !r1 && !r2 && !bt) ||
                     (epi.mode == MAFED_EPI_NONE && r1 && epi.res1_bf16 && r2 && !bt) || (!pair && epi.mode == MAFED_EPI_NONE && !r1 && !r2 && bt);
   if (colsum && !fast) return false;
+  // the weight-gradient instantiations (both operands reduction-major) carry the bias / beta epilogues only (PPEpilogue PLAIN_ONLY)
+  if (a_ks && b_ks && (epi.mode != MAFED_EPI_NONE || r1 || r2 || colsum)) return false;
   pr.A = (const bf16_t*)A; pr.B = (const bf16_t*)B; pr.C = C;
   pr.bias = epi.bias; pr.aux = epi.aux; pr.res1 = epi.res1; pr.res2 = epi.res2; pr.colsum = colsum;
   pr.lda = lda; pr.ldb = ldb; pr.ldc = ldc;

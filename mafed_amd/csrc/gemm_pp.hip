@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
 
   // ---- epilogue (gemm_pp_epilogue.h): straight from the accumulators, 64-byte row segments per store instruction -----------------
   auto epilogue = [&](int tm, int tn) {
-    PPEpilogue<MT, NT, CT>::run(acc, cq, (int64_t)tm * TM + li, (int64_t)tn * TN + wave * NT * 16, lane,
+    PPEpilogue<MT, NT, CT, false, (A_KS && B_KS)>::run(acc, cq, (int64_t)tm * TM + li, (int64_t)tn * TN + wave * NT * 16, lane,
                                 reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64);
   };
 

@@ -37,7 +37,11 @@ __device__ __forceinline__ f32x4 pp_acc_read(const f32x4& a) {
   }
 }
 
-template <int MT, int NT, typename CT, bool ACC_AGPR = false>
+// PLAIN_ONLY: the instantiation only ever sees bias / beta epilogues (the weight-gradient kernels: both operands reduction-major);
+// leaving the activation code out keeps those kernels below the register count at which hipcc starts to spill (3 VGPRs with the
+// polynomial GELU compiled in -- a spill anywhere puts a vmcnt(0) into the K loop).  The dispatcher never sends them anything else
+// (pp_fill_problem).
+template <int MT, int NT, typename CT, bool ACC_AGPR = false, bool PLAIN_ONLY = false>
 struct PPEpilogue {
   static constexpr bool PAIR = sizeof(CT) == 2;
   static constexpr int NPAIR = NT / 2;
@@ -210,6 +214,11 @@ struct PPEpilogue {
     const int mode = cq.mode;
     const bool r1 = cq.res1 != nullptr, r1h = r1 && cq.res1_bf16, r2 = cq.res2 != nullptr;
     const bool bt = cq.beta != 0.f;
+    if constexpr (PLAIN_ONLY) {
+      if (!PAIR && bt) fast<MAFED_EPI_NONE, 0, (PAIR ? 0 : 2)>(acc, cq, row0, colw, lane, scr);
+      else fast<MAFED_EPI_NONE, 0, 0>(acc, cq, row0, colw, lane, scr);
+      return;
+    }
     if (mode == MAFED_EPI_NONE && !r1 && !r2 && !bt) fast<MAFED_EPI_NONE, 0, 0>(acc, cq, row0, colw, lane, scr);
     else if (mode == MAFED_EPI_GELU && !r1 && !r2 && !bt) fast<MAFED_EPI_GELU, 0, 0>(acc, cq, row0, colw, lane, scr);
     else if (PAIR && mode == MAFED_EPI_GELU_BWD && !r1 && !r2 && !bt) fast<(PAIR ? MAFED_EPI_GELU_BWD : MAFED_EPI_NONE), (PAIR ? 1 : 0), 0>(acc, cq, row0, colw, lane, scr);

@@ -538,3 +538,28 @@ def test_embed_concat():
     assert torch.equal(dimg.cpu().view(B, P, h), dh0.view(B, P + T, h)[:, :P])
     ref_e = torch.zeros(V, h, dtype=torch.float64).index_add_(0, ids.reshape(-1), dh0.view(B, P + T, h)[:, P:].reshape(-1, h).double())
     assert_close(demb, ref_e, 1e-6, "embed grad")
+
+
+def test_fast_gelu_polynomials_against_erf():
+    """The bf16 MFMA epilogues' polynomial erf-GELU and its derivative (csrc/common.h, tools/gelu_poly_fit.py) over [-8, 8], read through
+    an fp32-output product C[m, :] = x_m (A = x in column 0, B = ones in column 0): |gelu err| <= 5e-5, |gelu' err| <= 5e-5 -- below
+    the bf16 rounding of the stored activation / gradient."""
+    ops = _ops()
+    M, N, K = 2048, 256, 256
+    x = torch.linspace(-8.0, 8.0, M).to(torch.bfloat16).float()          # bf16-representable arguments
+    A = torch.zeros(M, K); A[:, 0] = x
+    Bm = torch.zeros(N, K); Bm[:, 0] = 1.0
+    D = lambda v: v.to(DEV)
+    y = ops.gemm(D(A).to(torch.bfloat16), D(Bm).to(torch.bfloat16), False, True, out_dtype=torch.float32, epilogue=ops.EPI_GELU)
+    ref = F.gelu(x.double())
+    assert float((y[:, 0].double().cpu() - ref).abs().max()) <= 5e-5
+    assert torch.equal(y[:, 0], y[:, N - 1])
+    # derivative: C = dy * gelu'(u) with dy = 1 (A = ones in column 0), u = the saved pre-activation
+    A1 = torch.zeros(M, K); A1[:, 0] = 1.0
+    u = x.view(M, 1).repeat(1, N).contiguous()
+    g = ops.gemm(D(A1).to(torch.bfloat16), D(Bm).to(torch.bfloat16), False, True, out_dtype=torch.bfloat16, epilogue=ops.EPI_GELU_BWD,
+                 aux=D(u).to(torch.bfloat16))
+    xd = x.double().requires_grad_(True)
+    F.gelu(xd).sum().backward()
+    err = (g[:, 0].double().cpu() - xd.grad).abs()
+    assert float((err - 2.0 ** -8 * xd.grad.abs()).max()) <= 5e-5, "beyond the bf16 rounding of the stored gradient"

@@ -40,3 +40,11 @@ t_f = timed(lambda: ops.attn_fwd(qkv, B, S, H, D, rot, cos, sin, am))
 t_b = timed(lambda: ops.attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, am))
 fl = 4.0 * B * H * S * S * D
 print(f"attn B={B} H={H} S={S} D={D}: fwd {t_f:7.1f} us ({fl / t_f / 1e6:6.1f} TF dense-equiv)   bwd {t_b:7.1f} us ({2.5 * fl / t_b / 1e6:6.1f} TF)", flush=True)
+# kernel execution times (start/stop events on each launch: not limited by the host's ~10 us per call)
+from mafed_amd.profiler import KernelProfile
+with KernelProfile() as kp:
+    for _ in range(20):
+        ops.attn_fwd(qkv, B, S, H, D, rot, cos, sin, am)
+        ops.attn_bwd(qkv, out, dout, lse, B, S, H, D, rot, cos, sin, am)
+for tag, a in kp.summary().items():
+    print(f"   {tag:14s} {a['launches']:3d} launches  avg {a['avg_us']:7.2f} us", flush=True)
