@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--dump-profile", default=None, metavar="DIR", help="write the per-launch records behind `roofline` / `kernels` as CSV (tag, "
                     "algorithmic work, start ms, duration us) for the timed configuration and for the single-stream repeat")
     ap.add_argument("--no-secondary", action="store_true", help="skip the blended-schedule measurement (3 CE + 1 MAFED micro-batches)")
+    ap.add_argument("--no-teacher-cache-leg", action="store_true", help="skip the teacher-cache measurement (frozen-teacher states of the whole "
+                    "replay memory resident in HBM: 108 GB at 410M / 4000 samples)")
     ap.add_argument("--no-image-leg", action="store_true", help="skip the image-input measurement (CLIP-ViT-L/14 tower in front of the step)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: mafed_gemm_set_variant value")
     ap.add_argument("--no-pipeline-optimizer", action="store_true", help="AdamW in front of the next forward instead of under it")
@@ -362,6 +364,45 @@ def main():
         dump_profile(args.dump_profile, "kernel_profile_no_overlap.csv", kp1, rank)
         student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer = ov
         barrier()
+
+    # MI355X-only design point, reported BESIDE the headline (never instead of it: the step above runs the teacher forward, as SURVEY 8d
+    # defines it): the frozen teacher's distilled hidden states for this rank's whole replay memory stay resident in HBM
+    # (FeatureDistillation.build_teacher_cache: fp32 [layers, samples, S, h], filled once per task by the same kernels), a replay step
+    # gathers its 32 samples' rows instead of running the teacher forward
+    teacher_cache = None
+    if not args.no_teacher_cache_leg:
+        tr.join()
+        need = (cfg.num_hidden_layers - 1) * len(mem) * (P + T) * cfg.hidden_size * 4
+        free, _tot = torch.cuda.mem_get_info(dev)
+        if need + (24 << 30) <= free:
+            info = fd.build_teacher_cache(mem)
+            ntc = max(5, args.steps // 2)
+            for i in range(3):
+                tr.step(task_batch, 10_000 + i)
+            torch.cuda.synchronize()
+            barrier()
+            ttc = time.perf_counter()
+            for i in range(ntc):
+                rec_tc = tr.step(task_batch, 10_003 + i)
+            torch.cuda.synchronize()
+            barrier()
+            dtc = time.perf_counter() - ttc
+            t4 = torch.tensor([dtc], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+            dtc = float(t4.item())
+            tr.join()
+            teacher_cache = {"metric": "train samples/s, the headline step with the frozen teacher's hidden states of the whole replay memory "
+                                       "cached in HBM (a gather instead of the teacher forward; bit-identical teacher states)",
+                             "value": round(ntc * B * world / dtc, 3), "unit": "samples/s", "steps": ntc, "ms_per_step": round(dtc / ntc * 1e3, 3),
+                             "cache_GB_per_gpu": round(info["GB"], 1), "cached_samples_per_gpu": info["samples"], "fill_seconds": round(info["seconds"], 2),
+                             "final_loss": round(float(rec_tc["loss"]), 5)}
+            assert teacher_cache["final_loss"] == teacher_cache["final_loss"], "NaN loss in the teacher-cache leg"
+            log(f"teacher-cache leg: {ntc} steps in {dtc * 1e3:.1f} ms ({info['GB']:.1f} GB cached in {info['seconds']:.1f} s)")
+            fd.drop_teacher_cache()
+            torch.cuda.empty_cache()
+        else:
+            teacher_cache = {"value": None, "note": f"skipped: {need / 1e9:.0f} GB of teacher states do not fit beside {(_tot - free) / 1e9:.0f} GB in use"}
 
     # secondary metric: the reference's blended schedule -- bs 16 x accumulate 4, replay_interval 4: per optimiser
     # step three plain-CE micro-batches on task data and one MAFED micro-batch on memory data (scripts/run_seed42.sh:51-70)
@@ -568,6 +609,8 @@ def main():
             out["secondary"] = secondary
         if image_leg:
             out["image_input"] = image_leg
+        if teacher_cache:
+            out["teacher_cache"] = teacher_cache
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model, P, T)

@@ -157,6 +157,11 @@ class FeatureDistillation(CLStrategy):
         # data parallel only: masked means over the GLOBAL token counts (one small all-reduce per step; global_token_counts).  Off = the
         # reference's per-rank means.  True = default process group, or pass a group.
         self.exact_normaliser = kwargs.get("exact_normaliser", False)
+        # keep the frozen teacher's distilled hidden states for the whole replay memory resident in HBM (build_teacher_cache; filled by
+        # update() once per task).  Off by default: the reference runs the teacher forward in every replay step.
+        self.teacher_cache = bool(kwargs.get("teacher_cache", False))
+        self._tcache = None
+        self._mem_index = None
         self._prefetched = None
         self.last_layer_losses: Optional[torch.Tensor] = None  # [n_layers] device tensor of the last distill() call
         self.last_modality_losses: Optional[torch.Tensor] = None  # [n_layers, 2] (lang, vision)
@@ -167,9 +172,12 @@ class FeatureDistillation(CLStrategy):
         self._update_memory(dataset)
         self.loss_weights.update_weights(model, dataloader, self.task_id)
         self.task_id += 1
+        if getattr(self, "teacher_cache", False):   # opt-in: the new teacher's states for the whole memory, once per task
+            self.build_teacher_cache()
 
     def _update_model(self, model):
         """Teacher := frozen copy of the finished task's model (distillation.py:211-213)."""
+        self.drop_teacher_cache()   # states of the previous teacher
         self.past_model = deepcopy(model)
         self.past_model.eval()
         for p in self.past_model.parameters():
@@ -219,6 +227,7 @@ class FeatureDistillation(CLStrategy):
     def replay(self, model):
         """Memory batch -> replay CE (iff replay_coeff > 0 and task_id > 0) + distillation (distillation.py:84-103)."""
         batch = next(iter(self.mem_dataloader))
+        self._mem_index = batch.pop("memory_index", None)   # (HBMReplayBuffer.attach_index: rows of the teacher cache)
         n_ex = batch["input_ids"].size(0)
         do_replay = self.replay_coeff > 0 and self.task_id > 0
         pv = batch.get("pixel_values")
@@ -318,7 +327,9 @@ class FeatureDistillation(CLStrategy):
                 v.record_stream(side)
         kw = {"patch_embeddings": batch["patch_embeddings"]} if "patch_embeddings" in batch else {"pixel_values": batch["pixel_values"]}
         with torch.cuda.stream(side):
-            hs = [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=max(layers) + 1, **kw)]
+            hs = self._cached_teacher_states(max(layers) + 1)       # teacher cache: a gather instead of the forward
+            if hs is None:
+                hs = [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=max(layers) + 1, **kw)]
             ev = side.record_event()
         self._prefetched = (hs, ev, max(layers) + 1)
 
@@ -334,11 +345,77 @@ class FeatureDistillation(CLStrategy):
                 return hs
         pm = self.past_model
         with torch.no_grad():
+            cached = self._cached_teacher_states(n_hidden)
+            if cached is not None:
+                return cached
             if hasattr(pm, "hidden_states_upto"):
                 kw = {"patch_embeddings": batch["patch_embeddings"]} if "patch_embeddings" in batch else {"pixel_values": batch["pixel_values"]}
                 return [x.detach() for x in pm.hidden_states_upto(batch["input_ids"], batch["attention_mask"], n_hidden=n_hidden, **kw)]
             hs = pm(**batch, output_hidden_states=True, return_dict=True).hidden_states
             return [x.detach() for x in hs]
+
+    # ---- teacher cache (MI355X-only design point: 288 GB of HBM) ------------------------------------------------------------
+    def build_teacher_cache(self, mem=None, batch_size: Optional[int] = None) -> Dict[str, float]:
+        """The frozen teacher sees the same stored samples for a whole task: run it ONCE over (this rank's shard of) the replay
+        memory and keep the distilled hidden states resident -- fp32 [n_layers, n, S, h], 27 MB per sample at 410M = 108 GB for the
+        reference's 4000-sample memory, sharded 1/N under data parallelism.  A replay step then gathers its batch's rows
+        (``memory_index`` from the buffer) instead of running the teacher forward: 5.2 of the step's 22.5 TFLOP.  The cache is
+        written by the same kernels on the same batch shapes as the per-step forward (the tail re-runs the last full batch), so the
+        cached step is bit-identical to the uncached one.  Dropped whenever the teacher changes (``_update_model``)."""
+        import time
+        mem = mem if mem is not None else self.mem_dataloader
+        pm = self.past_model
+        if pm is None or not hasattr(pm, "hidden_states_upto") or not hasattr(mem, "data") or len(mem) == 0:
+            raise RuntimeError("teacher cache: needs the native teacher and a resident replay memory (HBMReplayBuffer)")
+        layers = list(self.loss_weights.get_distillation_layers())
+        n_hidden = max(layers) + 1
+        lo, hi = mem.shard() if hasattr(mem, "shard") else (0, len(mem))
+        B = int(batch_size or mem.batch_size)
+        data = mem.data
+        dev = pm.flat_params.device
+        T = data["input_ids"].shape[1]
+        S, h = self.num_vision_tokens + T, pm.config.hidden_size
+        n = hi - lo
+        t0 = time.time()
+        states = torch.empty((len(layers), n, S, h), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for i in range(lo, hi, B):
+                j = min(i, max(lo, hi - B))            # the tail re-runs the last FULL batch: same kernel shapes as in the step
+                e = min(j + B, hi)
+                hs = pm.hidden_states_upto(data["input_ids"][j:e], data["attention_mask"][j:e], patch_embeddings=data["patch_embeddings"][j:e],
+                                           n_hidden=n_hidden)
+                for k, l in enumerate(layers):
+                    states[k, j - lo: e - lo] = hs[l].view(e - j, S, h)
+        torch.cuda.synchronize(dev)
+        mem.attach_index = True
+        mem._next = None      # (a batch gathered ahead carries no index)
+        self._tcache = {"states": states, "layers": layers, "lo": lo, "n": n, "S": S, "h": h, "mem": mem, "mem_len": len(mem),
+                        "layer_off": (torch.arange(len(layers), device=dev, dtype=torch.int64) * (n * S)).view(-1, 1, 1),
+                        "ar": torch.arange(S, device=dev, dtype=torch.int64).view(1, 1, S)}
+        return {"GB": states.numel() * 4 / 1e9, "samples": n, "seconds": time.time() - t0}
+
+    def drop_teacher_cache(self) -> None:
+        tc = getattr(self, "_tcache", None)
+        if tc is not None and hasattr(tc["mem"], "attach_index"):
+            tc["mem"].attach_index = False
+            tc["mem"]._next = None
+        self._tcache = None
+
+    def _cached_teacher_states(self, n_hidden: Optional[int]):
+        """hidden_states[l] of the cached teacher for the batch handed out last, or None when the cache does not cover it."""
+        tc, idx = getattr(self, "_tcache", None), getattr(self, "_mem_index", None)
+        if tc is None or idx is None or tc["mem"] is not self.mem_dataloader or len(tc["mem"]) != tc["mem_len"]:
+            return None
+        layers = list(self.loss_weights.get_distillation_layers())
+        if layers != tc["layers"]:
+            return None
+        B, S, h = idx.numel(), tc["S"], tc["h"]
+        rows = (tc["layer_off"] + ((idx.to(tc["ar"].device) - tc["lo"]) * S).view(1, B, 1) + tc["ar"]).to(torch.int32).view(-1)
+        out = ops.gather_rows(tc["states"].view(-1, h), rows)          # ONE launch for every distilled layer
+        hs = [None] * (max(layers) + 1)
+        for k, l in enumerate(layers):
+            hs[l] = out[k * B * S: (k + 1) * B * S].view(B, S, h)
+        return hs
 
     def _exact_group(self):
         """The process group of the exact-normaliser all-reduce (``exact_normaliser`` = True: the default group), or None."""

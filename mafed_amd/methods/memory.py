@@ -36,6 +36,7 @@ class HBMReplayBuffer:
         self.last_ready_event = None
         self.max_label_rows: Optional[int] = None
         self.attach_label_hint = True   # batches carry ``max_label_rows`` (row-sparse LM head in training)
+        self.attach_index = False       # batches carry ``memory_index`` [B] (device int64): which stored samples they are (teacher cache)
 
     def __len__(self) -> int:
         t = self.data["input_ids"]
@@ -85,6 +86,11 @@ class HBMReplayBuffer:
             batch = self._draw()
             self._next = (batch, self._stream.record_event())
 
+    def shard(self):
+        """[lo, hi): the stored samples this rank draws from."""
+        n = len(self)
+        return (n * self.rank) // self.world_size, (n * (self.rank + 1)) // self.world_size
+
     def _draw(self) -> Dict[str, torch.Tensor]:
         n = len(self)
         if n == 0:
@@ -100,6 +106,8 @@ class HBMReplayBuffer:
         else:
             idx = idx.to(self.device)
         out = {k: v.index_select(0, idx) for k, v in self.data.items()}
+        if self.attach_index:
+            out["memory_index"] = idx
         if getattr(self, "max_label_rows", None) is not None and self.attach_label_hint:
             out["max_label_rows"] = self.max_label_rows
         return out

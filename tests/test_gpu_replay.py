@@ -195,3 +195,71 @@ def test_mafed_with_hbm_buffer_at_bench_size():
     b = _run(fd2, m2, batches, n_steps, pipeline=False, task_batch=task_batch)
     # bf16 backward noise floor (fp32 split-K atomics): 2e-3 relative gradient norm per step
     _compare(a, b, 2e-3, 2e-2, 1e-3)
+
+
+def test_teacher_cache_steps_are_bit_identical_to_the_teacher_forward():
+    """``build_teacher_cache``: the frozen teacher's distilled hidden states of the whole replay memory, written once by the same kernels
+    on the same batch shapes; a replay step then gathers its rows instead of running the teacher.  The gathered states equal a fresh
+    teacher forward on the same samples bit for bit (any batch, including the ragged tail of the memory); losses, gradient norms and
+    parameters of cached steps equal the uncached run (to the run-to-run noise of the backward's fp32 atomics), the teacher forward does
+    not run, and changing the teacher drops the cache."""
+    from mafed_amd import FeatureDistillation, Trainer
+    from mafed_amd.methods import HBMReplayBuffer
+    cfg = tiny_cfg("m64")
+    t = TINY["m64"]
+    B, T = t["B"], t["T"]
+    n_mem = 5 * B + 3                       # a ragged tail: the fill re-runs the last full batch
+    sd = R.init_weights(cfg, seed=31, bias_std=0.02, ln_jitter=0.05)
+    tsd = R.perturb(sd, seed=32, std=5e-3)
+    data = R.make_batch(cfg, n_mem, T, seed=33, pad=True, n_answer=3)
+    data["patch_embeddings"] = data["patch_embeddings"].to(torch.bfloat16).float()   # the buffer stores bf16 features
+
+    def run(cached):
+        model, teacher = _model(cfg, sd, torch.float32), _model(cfg, tsd, torch.float32)
+        opts = types.SimpleNamespace(tasks=["a", "b"], batch_size=B, seed=3, pin_mem=False, accumulate_grad_batches=1)
+        fd = FeatureDistillation(memory_size=10, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                                 distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                                 gamma=0.5, distillation_layer=None)
+        fd._update_model(teacher)
+        fd.task_id = 1
+        fd.num_vision_tokens = cfg.num_vision_tokens
+        mem = HBMReplayBuffer(B, DEV, seed=9)
+        mem.add(data)
+        fd.mem_dataloader = mem
+        calls = []
+        if cached:
+            info = fd.build_teacher_cache()
+            assert info["samples"] == n_mem and mem.attach_index
+            layers = fd.loss_weights.get_distillation_layers()
+            for idx in (torch.arange(B), torch.arange(n_mem - B, n_mem), torch.tensor([0, n_mem - 1, 7, B, 2 * B + 1, 3, n_mem - 2, 11][:B])):
+                idx = idx.to(DEV)
+                fd._mem_index = idx
+                got = fd._cached_teacher_states(max(layers) + 1)
+                want = fd.past_model.hidden_states_upto(mem.data["input_ids"][idx], mem.data["attention_mask"][idx],
+                                                        patch_embeddings=mem.data["patch_embeddings"][idx], n_hidden=max(layers) + 1)
+                for l in layers:
+                    assert torch.equal(got[l], want[l].view_as(got[l])), f"cached teacher state of layer {l} differs from the forward"
+            fd._mem_index = None
+            orig = fd.past_model.hidden_states_upto
+            fd.past_model.hidden_states_upto = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        tr = Trainer(model, fd, _conf(lr=1e-3), task_id=1, pipeline_optimizer=True)
+        task = {k: v[:B].to(DEV) for k, v in data.items()}
+        losses, gns = [], []
+        for i in range(4):
+            rec = tr.step(task, i)
+            losses.append(rec["loss"]); gns.append(rec["grad_norm"])
+        tr.join()
+        torch.cuda.synchronize()
+        assert not calls, "the teacher forward ran although its states are cached"
+        out = ([float(x) for x in losses], [float(x) for x in gns], model.flat_params.clone())
+        if cached:
+            fd._update_model(model)
+            assert fd._tcache is None and not mem.attach_index, "a new teacher must drop the cached states"
+        return out
+
+    la, ga, pa = run(False)
+    lb, gb, pb = run(True)
+    assert la[0] == lb[0] and ga[0] == gb[0], (la, lb, ga, gb)     # same weights, same batch, same teacher bits
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(la, lb)) and all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(ga, gb)), (la, lb, ga, gb)
+    assert float((pa - pb).abs().max()) <= 1e-6
+    assert len(set(la)) == 4

@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r3m
-for lib in libmafed_hip lib_attn3 lib_attn4 lib_attn1; do
-  echo "== $lib" >> gpurun_out/r3m/attn.log
-  MAFED_HIP_LIB=$PWD/mafed_amd/$lib.so timeout -k 10 120 python tools/attn_bench.py >> gpurun_out/r3m/attn.log 2>&1 || exit 1
+mkdir -p gpurun_out/r3n
+for nc in 0 1 0 1; do
+echo "== NOCOLSUM=$nc" >> gpurun_out/r3n/dfc2.log
+GEMM_BENCH_NOCOLSUM=$nc GEMM_BENCH_EPI=1 GEMM_BENCH_ONLY=dfc2 timeout -k 10 120 python tools/gemm_bench.py 700,701 >> gpurun_out/r3n/dfc2.log 2>&1 || exit 1
 done
+GEMM_BENCH_ONLY=dfc2 timeout -k 10 120 python tools/gemm_bench.py 700,701 >> gpurun_out/r3n/dfc2.log 2>&1
