@@ -1,6 +1,3 @@
-mkdir -p gpurun_out/r3n
-for nc in 0 1 0 1; do
-echo "== NOCOLSUM=$nc" >> gpurun_out/r3n/dfc2.log
-GEMM_BENCH_NOCOLSUM=$nc GEMM_BENCH_EPI=1 GEMM_BENCH_ONLY=dfc2 timeout -k 10 120 python tools/gemm_bench.py 700,701 >> gpurun_out/r3n/dfc2.log 2>&1 || exit 1
-done
-GEMM_BENCH_ONLY=dfc2 timeout -k 10 120 python tools/gemm_bench.py 700,701 >> gpurun_out/r3n/dfc2.log 2>&1
+mkdir -p gpurun_out/r3o
+timeout -k 10 600 python -m pytest tests/test_gpu_replay.py -m gpu -x -q > gpurun_out/r3o/tests.log 2>&1 || exit 1
+timeout -k 10 400 python bench.py --no-secondary --no-image-leg --no-cpu-baseline > gpurun_out/r3o/bench.json 2> gpurun_out/r3o/bench.err
