@@ -1,3 +1,7 @@
-mkdir -p gpurun_out/r3o
-timeout -k 10 600 python -m pytest tests/test_gpu_replay.py -m gpu -x -q > gpurun_out/r3o/tests.log 2>&1 || exit 1
-timeout -k 10 400 python bench.py --no-secondary --no-image-leg --no-cpu-baseline > gpurun_out/r3o/bench.json 2> gpurun_out/r3o/bench.err
+set -e
+OUT=gpurun_out/profiles_new
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# the kernel-trace half of tools/make_profiles.sh (the trace must not contain the teacher-cache leg)
+sed -n '/^rm -rf gpurun_out\/prof_kt$/,/^python3 tools\/step_timeline.py/p' tools/make_profiles.sh > /tmp/kt_part.sh
+bash /tmp/kt_part.sh

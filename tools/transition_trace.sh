@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_tr
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_tr -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --steps 6 --warmup 4 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_tr -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --steps 6 --warmup 4 > /dev/null 2>&1
 kt=$(find gpurun_out/prof_tr -name "*kernel_trace.csv" | head -1)
 python3 - "$kt" <<'PY'
 import csv, re, sys
