@@ -269,4 +269,4 @@ def test_configs4_step_fed_by_the_resident_replay_memory():
     assert all(l == l and l < 20.0 for l in la), la
     assert la[0] == lb[0], (la, lb)                       # same weights, same batch: the same forward bit for bit
     assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(la, lb)), (la, lb)
-    assert abs(ca - cb) <= 1e-7 * abs(cb)
+    assert abs(ca - cb) <= 2e-6 * abs(cb)   # (sum over 1.4 G parameters after three AdamW steps: atomics noise in the gradients)
