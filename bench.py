@@ -294,6 +294,8 @@ def main():
                                  weight_decay=0.01, optim="adamw", warmup_perc=0.1)
     tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
                  bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt, incremental_norm=not args.no_incremental_norm)
+    if args.gemm_variant is not None:
+        tr.contention_aware = False   # an explicit kernel choice is not overridden under N > 1
     task_batch = mem.sample()  # dropped by a replay step, as in the reference
 
     def barrier():

@@ -333,6 +333,10 @@ int mafed_attn_set_variant(int variant);
 int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                               const int64_t* attention_mask, int T, void* out, float* lse, void* stream);
 
+/* Tuning helper (not on the product path): occupies `blocks` CUs with one 512-thread block each (`lds_bytes` of LDS) for ~`cycles` shader
+ * clocks -- a stand-in for a long-running collective kernel when measuring GEMMs with part of the chip taken (tools/contention_bench.py). */
+int mafed_tune_occupy(int blocks, int lds_bytes, long long cycles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

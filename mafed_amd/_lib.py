@@ -61,6 +61,7 @@ SIGNATURES = {
     "mafed_adamw_step_zero_grad": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
     "mafed_distill_combine": (_i, [_p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p]),
     "mafed_optim_advance": (_i, [_p, _d, _l, _l, _d, _d, _p, _p]),
+    "mafed_tune_occupy": (_i, [_i, _i, C.c_longlong, _p]),
     "mafed_gradnorm_finish_advance": (_i, [_p, _i, _f, _p, _p, _p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_pad_text_rows": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),

@@ -89,5 +89,34 @@ extern "C" int mafed_prof_collect(int* tags, double* work, float* ms, float* sta
 
 extern "C" const char* mafed_prof_tag_name(int tag) { return (tag >= 0 && tag < mafed::K_TAG_COUNT) ? mafed::kTagNames[tag] : "?"; }
 
+// ---- tuning helper ----------------------------------------------------------------------------------------------------------
+// Occupies `blocks` CUs (one 512-thread block with `lds_bytes` of LDS each) for about `cycles` shader clocks: a stand-in for a
+// long-running collective kernel when measuring how a GEMM behaves with part of the chip taken (tools/contention_bench.py).
+namespace mafed {
+__global__ __launch_bounds__(512) void occupy_kernel(long long cycles, unsigned* sink) {
+  extern __shared__ char smem[];
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  unsigned acc = 0;
+  while ((long long)__builtin_readcyclecounter() - t0 < cycles) {   // every wave reaches this exit: bounded by the clock
+    acc += (unsigned)smem[threadIdx.x & 63];
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (acc == 0xffffffffu && sink) sink[0] = acc;
+}
+}  // namespace mafed
+extern "C" int mafed_tune_occupy(int blocks, int lds_bytes, long long cycles, void* stream) {
+  using namespace mafed;
+  MAFED_CHECK_ARG(blocks >= 1 && blocks <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && cycles >= 0 && cycles <= (1ll << 33),
+                  "tune_occupy: bad arguments");
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+    set_error("tune_occupy: cannot raise the LDS limit");
+    return MAFED_ELAUNCH;
+  }
+  occupy_kernel<<<dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream>>>(cycles, nullptr);
+  MAFED_CHECK_LAUNCH("tune_occupy");
+  return MAFED_OK;
+}
+
 extern "C" int mafed_version(void) { return 110; }
 extern "C" const char* mafed_last_error_string(void) { return mafed::g_err; }

@@ -669,6 +669,21 @@ class VLPythiaForCausalLM(nn.Module):
         return {l: t.view(sv["B"], S, -1) for l, t in taps.items()}
 
     def _engine_backward(self, sv, dloss: Optional[torch.Tensor], dhidden: Sequence[Optional[torch.Tensor]], taps=None):
+        # Data parallel, last micro-batch of a window: RCCL's all-reduce kernels hold a workgroup per channel for milliseconds while this
+        # backward runs.  The persistent GEMMs assume all 256 of their blocks are resident at once -- with 8 CUs taken the late blocks run
+        # a second wave and a launch takes 1.7x as long (tools/contention_bench.py: qkv 61.8 -> 105 us, grouped dW 440 -> 785), where the
+        # 128 x 128 kernels' many small blocks lose 1.1 - 1.45x.  So this backward runs on those (Trainer sets the flag).
+        if getattr(self, "contended_backward", False) and self.flat_params.is_cuda:
+            from mafed_amd import _lib as _l
+            lib = _l.load()
+            lib.mafed_gemm_set_variant(700)
+            try:
+                return self._engine_backward_impl(sv, dloss, dhidden, taps)
+            finally:
+                lib.mafed_gemm_set_variant(701)
+        return self._engine_backward_impl(sv, dloss, dhidden, taps)
+
+    def _engine_backward_impl(self, sv, dloss: Optional[torch.Tensor], dhidden: Sequence[Optional[torch.Tensor]], taps=None):
         self._bw_serial = getattr(self, "_bw_serial", 0) + 1   # lets a gradient hook tell which backward sweep reported a range
         cfg, cd = self.config, self.compute_dtype
         B, T, P, S = sv["B"], sv["T"], sv["P"], sv["S"]

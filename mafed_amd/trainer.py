@@ -55,6 +55,7 @@ class Trainer:
         # global-norm clip from per-range partials launched by the backward as each range becomes final (single process only: under
         # DDP the gradient hook belongs to the reducer; plugins that touch gradients outside the model's backward keep the one-pass norm)
         self.incremental_norm = bool(incremental_norm)
+        self.contention_aware = True   # DDP: 128 x 128 GEMM kernels while collectives share the chip (model._engine_backward)
         self.global_step = 0
         self._one = None
         self.optimizer.zero_grad()
@@ -92,6 +93,8 @@ class Trainer:
             self.reducer.enabled = window_end  # the gradient mean runs only on the last micro-batch of an accumulation window
             if window_end:
                 self.reducer.begin_window()
+            # collectives run beside this backward: the model keeps its GEMMs off the one-block-per-CU persistent kernels meanwhile
+            self.model.contended_backward = bool(window_end and self.reducer.world > 1 and self.contention_aware)
         inc_norm = (window_end and self.reducer is None and self.grad_norm and self.grad_norm > 0 and self.incremental_norm
                     and getattr(self.cl_method, "grads_only_through_model", False) and hasattr(self.model, "grad_ready_hook")
                     and self.model.flat_grads.is_cuda)
@@ -118,6 +121,9 @@ class Trainer:
             self.cl_method.update_after_backward(model=self.model)  # on_before_optimizer_step
             if self.reducer is not None:
                 self.reducer.wait()
+                if self.reducer.world > 1 and self.contention_aware and torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
+                    # the next step's teacher forward (persistent GEMMs) starts behind the last bucket's collective, not beside it
+                    self.cl_method.backward_done_event = torch.cuda.current_stream().record_event()
             if self.grad_norm and self.grad_norm > 0:
                 gn = self.optimizer.clip_grad_norm_(self.grad_norm, fuse_advance=True)
                 # (fused finish + advance leaves the norm in a log slot of its own; the one-pass form returns clip_out[0], overwritten next step)

@@ -270,3 +270,31 @@ def test_configs4_step_fed_by_the_resident_replay_memory():
     assert la[0] == lb[0], (la, lb)                       # same weights, same batch: the same forward bit for bit
     assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(la, lb)), (la, lb)
     assert abs(ca - cb) <= 2e-6 * abs(cb)   # (sum over 1.4 G parameters after three AdamW steps: atomics noise in the gradients)
+
+
+def test_contended_backward_keeps_off_the_persistent_kernels():
+    """Under data parallelism the Trainer flags the backward that runs beside RCCL's collectives (``model.contended_backward``): its
+    GEMMs then take the 128 x 128 kernels (many small blocks) instead of the one-block-per-CU persistent ones, whose static tile
+    schedule takes 1.7x as long with a few CUs occupied (tools/contention_bench.py).  Same gradients either way."""
+    from mafed_amd import _lib
+    lib = _lib.load()
+    cfg, student, fd = _setup(preset="410m")
+    batch = _batch(cfg)
+    n0 = lib.mafed_gemm_pp_launches()
+    loss_a, grads_a = _replay_grads(student, fd, batch)
+    n_plain = lib.mafed_gemm_pp_launches() - n0
+    assert n_plain > 150, "forward and backward of the 410M step run on the persistent kernels"
+    student.contended_backward = True
+    n1 = lib.mafed_gemm_pp_launches()
+    loss_b, grads_b = _replay_grads(student, fd, batch)
+    n_cont = lib.mafed_gemm_pp_launches() - n1
+    student.contended_backward = False
+    assert loss_a == loss_b                                   # the forward is the same launches
+    assert 0 < n_cont < n_plain - 80, (n_plain, n_cont)       # forward (student + teacher) still persistent, the backward is not
+    den = float(grads_a.norm())
+    assert float((grads_a - grads_b).norm()) <= 2e-3 * den    # two tilings of the same bf16 products
+    # the switch is scoped to the backward: the next forward is back on the persistent kernels
+    n2 = lib.mafed_gemm_pp_launches()
+    fd.mem_dataloader = [dict(batch)]
+    fd.replay(student)
+    assert lib.mafed_gemm_pp_launches() - n2 > 80
