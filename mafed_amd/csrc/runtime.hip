@@ -93,7 +93,7 @@ extern "C" const char* mafed_prof_tag_name(int tag) { return (tag >= 0 && tag < 
 // Occupies `blocks` CUs (one 512-thread block with `lds_bytes` of LDS each) for about `cycles` shader clocks: a stand-in for a
 // long-running collective kernel when measuring how a GEMM behaves with part of the chip taken (tools/contention_bench.py).
 namespace mafed {
-__global__ __launch_bounds__(512) void occupy_kernel(long long cycles, unsigned* sink) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(8))) void occupy_kernel(long long cycles, unsigned* sink) {
   extern __shared__ char smem[];
   const long long t0 = (long long)__builtin_readcyclecounter();
   unsigned acc = 0;
@@ -106,6 +106,12 @@ __global__ __launch_bounds__(512) void occupy_kernel(long long cycles, unsigned*
 }  // namespace mafed
 extern "C" int mafed_tune_occupy(int blocks, int lds_bytes, long long cycles, void* stream) {
   using namespace mafed;
+  if (blocks < 0) {   // -n: n light blocks of 256 threads (one wave per SIMD, a handful of registers, no LDS): a co-residency probe
+    MAFED_CHECK_ARG(blocks >= -4096 && cycles >= 0 && cycles <= (1ll << 33), "tune_occupy: bad arguments");
+    occupy_kernel<<<dim3(-blocks), dim3(256), 0, (hipStream_t)stream>>>(cycles, nullptr);
+    MAFED_CHECK_LAUNCH("tune_occupy(light)");
+    return MAFED_OK;
+  }
   MAFED_CHECK_ARG(blocks >= 1 && blocks <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && cycles >= 0 && cycles <= (1ll << 33),
                   "tune_occupy: bad arguments");
   if (lds_bytes > 64 * 1024 &&

@@ -1,7 +1,5 @@
-set -e
-OUT=gpurun_out/profiles_new
-mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# the kernel-trace half of tools/make_profiles.sh (the trace must not contain the teacher-cache leg)
-sed -n '/^rm -rf gpurun_out\/prof_kt$/,/^python3 tools\/step_timeline.py/p' tools/make_profiles.sh > /tmp/kt_part.sh
-bash /tmp/kt_part.sh
+mkdir -p gpurun_out/r3r
+for k in 0 4 8 12 0 6; do
+  echo "== MAFED_OLD_LAYERS=$k" >> gpurun_out/r3r/old.log
+  MAFED_OLD_LAYERS=$k timeout -k 10 200 python bench.py --no-secondary --no-image-leg --no-cpu-baseline --no-kernel-profile --no-teacher-cache-leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> gpurun_out/r3r/old.log || exit 1
+done

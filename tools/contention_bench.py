@@ -17,13 +17,15 @@ rn = lambda *s: torch.randn(s, device=dev, generator=g).to(BF)
 SHAPES = [("qkv", False, True, M, 3072, 1024), ("dense", False, True, M, 1024, 1024), ("fc1", False, True, M, 4096, 1024),
           ("dfc1", False, False, M, 1024, 4096), ("dao", False, False, M, 1024, 1024)]
 side = torch.cuda.Stream()
+# negative entries: that many LIGHT blocks (256 threads, a handful of registers, no LDS) -- can small kernels share CUs with a persistent block?
+OCC = [int(v) for v in os.environ.get("CONTENTION_OCC", "8,16,32").split(",")]
 
 
 def timed(fn, occupy, reps=8):
     torch.cuda.synchronize()
     if occupy:
         with torch.cuda.stream(side):
-            _lib.check(lib.mafed_tune_occupy(occupy, 96 * 1024, int(6e6), side.cuda_stream), "occupy")   # ~3 ms at 2 GHz
+            _lib.check(lib.mafed_tune_occupy(occupy, 96 * 1024 if occupy > 0 else 0, int(6e6), side.cuda_stream), "occupy")   # ~3 ms at 2 GHz
         torch.cuda._sleep(200000)   # let the occupier's blocks take their CUs first (~0.1 ms)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -45,7 +47,7 @@ for name, tA, tB, m, n, k in SHAPES:
         fn()
         base = min(timed(fn, 0) for _ in range(3))
         row += f" | v{v}: free {base:6.1f} us"
-        for occ in (8, 16, 32):
+        for occ in OCC:
             t = min(timed(fn, occ) for _ in range(3))
             row += f", {occ} CUs taken {t:6.1f} ({t / base:4.2f}x)"
     print(row, flush=True)
