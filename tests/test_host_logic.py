@@ -265,3 +265,24 @@ def test_every_ops_attribute_the_package_uses_exists():
             if not hasattr(ops, m.group(1)):
                 missing.add((os.path.basename(f), m.group(1)))
     assert not missing, missing
+
+
+def test_runtime_env_is_opt_in_and_respects_the_environment(monkeypatch):
+    """Importing the package sets no HIP runtime option; apply_recommended_runtime_env() sets the tuned ones unless exported already,
+    explicit overrides win, and a call after the runtime initialised warns instead of pretending."""
+    import warnings
+    import mafed_amd
+    from mafed_amd import runtime_env as RE
+    monkeypatch.delenv("HIP_FORCE_DEV_KERNARG", raising=False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    monkeypatch.setattr(RE, "_hip_initialised", lambda: False)
+    env = mafed_amd.apply_recommended_runtime_env()
+    assert env["HIP_FORCE_DEV_KERNARG"] == "1" and env["GPU_MAX_HW_QUEUES"] == "6"        # an exported value wins over the recommendation
+    env = mafed_amd.apply_recommended_runtime_env({"GPU_MAX_HW_QUEUES": "3"})
+    assert env["GPU_MAX_HW_QUEUES"] == "3"                                                # an explicit override wins over the environment
+    monkeypatch.delenv("HIP_FORCE_DEV_KERNARG", raising=False)
+    monkeypatch.setattr(RE, "_hip_initialised", lambda: True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = mafed_amd.apply_recommended_runtime_env()
+    assert env["HIP_FORCE_DEV_KERNARG"] is None and any("no effect" in str(x.message) for x in w)
