@@ -272,7 +272,8 @@ def test_runtime_env_is_opt_in_and_respects_the_environment(monkeypatch):
     explicit overrides win, and a call after the runtime initialised warns instead of pretending."""
     import warnings
     import mafed_amd
-    from mafed_amd import runtime_env as RE
+    import importlib
+    RE = importlib.import_module("mafed_amd.runtime_env")   # (the package re-exports a function of the same name)
     monkeypatch.delenv("HIP_FORCE_DEV_KERNARG", raising=False)
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
     monkeypatch.setattr(RE, "_hip_initialised", lambda: False)
