@@ -224,3 +224,35 @@ def test_short_reductions_stay_on_the_small_tile_kernel():
     n0 = lib.mafed_gemm_pp_launches()
     ops.gemm(d, a, True, False, out_dtype=F32)
     assert lib.mafed_gemm_pp_launches() == n0
+
+
+def test_grouped_call_falls_back_to_one_launch_per_problem():
+    """Shapes no persistent configuration tiles (or more than 16 problems): mafed_gemm_grouped runs the products one by one through the
+    ordinary dispatcher -- same results, no persistent launch."""
+    ops = _ops()
+    lib = _lib()
+    lib.mafed_gemm_set_variant(701)
+    g = torch.Generator().manual_seed(10)
+    shapes = [(200, 128, 64), (128, 256, 192), (96, 64, 128)]          # ragged rows / short reductions: nothing for 144 / 128 / 256-row tiles
+    probs, refs = [], []
+    for (M, N, K) in shapes:
+        A = _int_mat((K, M), g).to(DEV, BF)
+        B = _int_mat((K, N), g).to(DEV, BF)
+        c0 = _int_mat((M, N), g).to(DEV, F32)
+        probs.append(dict(A=A, B=B, out=c0.clone(), beta=1.0))
+        refs.append(_ref(A.float().cpu(), B.float().cpu(), True, False) + c0.double().cpu())
+    n0 = lib.mafed_gemm_pp_launches()
+    ops.gemm_grouped(probs, True, False)
+    assert lib.mafed_gemm_pp_launches() == n0
+    for q, r in zip(probs, refs):
+        assert float((q["out"].double().cpu() - r).abs().max()) == 0.0
+    # 17 tileable problems exceed one launch's table: also one by one (each may still take the persistent kernel on its own)
+    many = []
+    for i in range(17):
+        A = _int_mat((256, 128), g).to(DEV, BF)
+        B = _int_mat((256, 256), g).to(DEV, BF)
+        many.append(dict(A=A, B=B, out=torch.zeros((128, 256), dtype=F32, device=DEV), beta=1.0))
+    ops.gemm_grouped(many, True, False)
+    for q in many:
+        r = _ref(q["A"].float().cpu(), q["B"].float().cpu(), True, False)
+        assert float((q["out"].double().cpu() - r).abs().max()) == 0.0
