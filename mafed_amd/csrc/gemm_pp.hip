@@ -66,9 +66,13 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
 
 __device__ __forceinline__ int pp_f2(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }                 // [k][64] image: 32-byte chunk XOR
 
-// Register budget: two waves per SIMD of 224 registers leave 64 of the SIMD's 512 to a third wave, so that the AdamW / LayerNorm /
-// distillation kernels of the step's other streams (51 - 59 registers, no LDS) run BESIDE a persistent GEMM block instead of waiting
-// for it.  (amdgpu_num_vgpr counts half-registers of the unified VGPR + AGPR file on gfx950: N caps the kernel at 2 N.)
+// Register budget (tuning knob, default = no cap).  A persistent block owns its CU: with two waves per SIMD of 241 - 253 registers
+// (allocated as 248 - 256) nothing else fits on the SIMD, and the block cannot even START while any other wave is resident there
+// (tools/contention_bench.py, profiles/r03_contention_light.txt).  -DPP_VGPR_CAP=224 leaves 64 registers per SIMD to one wave of a
+// side-stream kernel: the bf16-output instantiations then spill 16 - 25 registers in their epilogues only (isolated times unchanged)
+// and do co-reside with a light kernel, the fp32-output ones spill 49 - 95 in the loop (grouped dW 731 vs 440 us); in the step the
+// capped build gained nothing, so the default stays uncapped.  (amdgpu_num_vgpr counts half-registers of the
+// unified VGPR + AGPR file on gfx950: N caps the kernel at 2 N.)
 #ifndef PP_VGPR_CAP
 #define PP_VGPR_CAP 256
 #endif
