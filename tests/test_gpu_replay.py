@@ -197,7 +197,8 @@ def test_mafed_with_hbm_buffer_at_bench_size():
     _compare(a, b, 2e-3, 2e-2, 1e-3)
 
 
-def test_teacher_cache_steps_are_bit_identical_to_the_teacher_forward():
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 2)])
+def test_teacher_cache_steps_are_bit_identical_to_the_teacher_forward(rank, world):
     """``build_teacher_cache``: the frozen teacher's distilled hidden states of the whole replay memory, written once by the same kernels
     on the same batch shapes; a replay step then gathers its rows instead of running the teacher.  The gathered states equal a fresh
     teacher forward on the same samples bit for bit (any batch, including the ragged tail of the memory); losses, gradient norms and
@@ -223,15 +224,16 @@ def test_teacher_cache_steps_are_bit_identical_to_the_teacher_forward():
         fd._update_model(teacher)
         fd.task_id = 1
         fd.num_vision_tokens = cfg.num_vision_tokens
-        mem = HBMReplayBuffer(B, DEV, seed=9)
+        mem = HBMReplayBuffer(B, DEV, seed=9, rank=rank, world_size=world)   # (rank 1 of 2: the cache covers this rank's shard only)
         mem.add(data)
         fd.mem_dataloader = mem
+        lo, hi = mem.shard()
         calls = []
         if cached:
             info = fd.build_teacher_cache()
-            assert info["samples"] == n_mem and mem.attach_index
+            assert info["samples"] == hi - lo and mem.attach_index
             layers = fd.loss_weights.get_distillation_layers()
-            for idx in (torch.arange(B), torch.arange(n_mem - B, n_mem), torch.tensor([0, n_mem - 1, 7, B, 2 * B + 1, 3, n_mem - 2, 11][:B])):
+            for idx in (torch.arange(lo, lo + B), torch.arange(hi - B, hi), torch.tensor([lo, hi - 1, lo + 7, lo + B, lo + 2 * B + 1, lo + 3, hi - 2, lo + 11][:B])):
                 idx = idx.to(DEV)
                 fd._mem_index = idx
                 got = fd._cached_teacher_states(max(layers) + 1)
