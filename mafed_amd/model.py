@@ -734,7 +734,9 @@ class VLPythiaForCausalLM(nn.Module):
             on_side(run, dY, X)
 
         # layer weight gradients, grouped: (dY, X, gradient) records wait here (the list keeps dY / X alive) until `flush_dw`
-        group_dw = cd == torch.bfloat16 and int(getattr(self, "dw_group_layers", 0)) > 0
+        # (beside collectives the weight gradients go back to one 128 x 128-kernel launch per product on the side streams, as in round 2:
+        #  a grouped call would fall back to eight serial launches on the dX chain's stream)
+        group_dw = cd == torch.bfloat16 and int(getattr(self, "dw_group_layers", 0)) > 0 and not getattr(self, "contended_backward", False)
         pending_dw: List[dict] = []
         pending_layers: List[int] = []
 
