@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="single stream (profiling: per-kernel durations without concurrency)")
     ap.add_argument("--no-overlap-teacher", action="store_true", help="teacher forward on the caller's stream (A/B)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="parameter-gradient work on the caller's stream (A/B)")
+    ap.add_argument("--contended-backward", action="store_true", help="N = 1 diagnostic: run the backward the way it runs under data parallelism "
+                    "(128 x 128 GEMM kernels, weight gradients per product on the side streams) -- what the kernel choice alone costs per GPU")
     ap.add_argument("--dw-group-layers", type=int, default=None, help="layers per grouped weight-gradient launch (0 = one launch per product)")
     ap.add_argument("--reduce-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
@@ -271,6 +273,8 @@ def main():
     if args.dw_group_layers is not None:
         student.dw_group_layers = args.dw_group_layers
     fd.exact_normaliser = bool(args.exact_normaliser)
+    if args.contended_backward:
+        student.contended_backward = True
     # the replay memory holds --memory-size samples (the reference's memory_size = 4000, scripts/run_seed42.sh) resident in HBM: bf16 patch
     # features [n, P, dv] (2.1 GB at 4000 x 256 x 1024) + int64 text tensors; generated on the device in chunks, rank-specific seeds
     n_mem = max(8 * B, args.memory_size)
