@@ -95,6 +95,7 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    avail = cores
     cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     B = 4
@@ -121,7 +122,8 @@ def cpu_baseline(model_name, P, T, seconds_hint=20.0):
         n += 1
     dt = time.time() - t0
     out = {"value": round(B * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": f"oracle fp32 CPU, VLPythia-{model_name}+MAFED distill step, batch {B} (of 32), {P} img + {T} txt tokens, {n} timed steps"}
+           "sample": f"oracle fp32 CPU, VLPythia-{model_name}+MAFED distill step, batch {B} (of 32), {P} img + {T} txt tokens, {n} timed steps; "
+                     f"{cores} threads used of {avail} the box exposes to this process (one GPU's CPU share is 16)"}
     del tr, sd, tsd
     # BASELINE.json configs[0], the reference's own CPU-runnable case, at its full size: VLPythia-160M naive finetune (no distillation),
     # batch 4, 64 image + 16 text tokens
@@ -311,20 +313,29 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     log(f"setup done: {args.model} B={B} P={P} T={T} dtype={args.dtype} world={world} backend={backend}")
+    def alloc_state():   # (device allocations of torch's caching allocator so far, reserved GB): a step that grows the pool calls hipMalloc,
+        ms = torch.cuda.memory_stats(dev)   # which synchronises the device -- the "2x warm-up steps" of the round-3 logs
+        return int(ms.get("num_device_alloc", 0)), ms.get("reserved_bytes.all.current", 0) / 1e9
+
     for i in range(args.warmup):
+        a0 = alloc_state()
         tw = time.perf_counter()
         tr.step(task_batch, i)
         torch.cuda.synchronize()
-        log(f"warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
+        a1 = alloc_state()
+        log(f"warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms (hipMalloc calls {a1[0] - a0[0]}, pool {a0[1]:.2f} -> {a1[1]:.2f} GB)")
     torch.cuda.synchronize()
     if tr.reducer is not None:
         tr.reducer.time_wait = True   # two event records per step on the compute stream (diagnostics of the N > 1 line)
     barrier()
     torch.cuda.synchronize()
+    a_timed0 = alloc_state()
+    c0 = time.thread_time()
     t0 = time.perf_counter()
     for i in range(args.steps):
         rec = tr.step(task_batch, args.warmup + i)
-    t_host = time.perf_counter() - t0  # host enqueue time (the GPU runs behind it)
+    t_host = time.perf_counter() - t0  # host enqueue wall time (includes standing behind the full launch queues)
+    c_host = time.thread_time() - c0   # CPU time of the enqueueing thread: the host's own work (autograd's backward thread not included)
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0  # this rank's own time, before the barrier
     barrier()
@@ -342,7 +353,9 @@ def main():
                     "reducer_wait_ms_max": [round(float(x[2]), 3) for x in allr]}
     dt = float(tmax.item())
     loss = float(rec["loss"])
-    log(f"timed region: {args.steps} steps in {dt * 1e3:.1f} ms (host enqueue {t_host * 1e3:.1f} ms), loss {loss:.5f}")
+    a_timed1 = alloc_state()
+    log(f"timed region: {args.steps} steps in {dt * 1e3:.1f} ms (host enqueue wall {t_host * 1e3:.1f} ms, CPU {c_host * 1e3:.1f} ms; "
+        f"hipMalloc calls inside {a_timed1[0] - a_timed0[0]}), loss {loss:.5f}")
     assert loss == loss, "NaN loss in the timed region"
 
     # live rooflines: N_PROF more steps of the SAME configuration (same streams / overlap) with every hot kernel launched
@@ -593,7 +606,11 @@ def main():
                "ranks_joined": ranks_joined, "dist_backend": backend, "runtime_env": runtime_env(),
                "replay_memory": {"samples": len(mem), "HBM_MB": round(sum(v.numel() * v.element_size() for v in mem.data.values() if v is not None) / 1e6, 1)},
                "step_tflops_algorithmic": round(flops_step / 1e12, 3),
-               "mfma_frac_whole_step": round(flops_exec * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5)}
+               "mfma_frac_whole_step": round(flops_exec * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5),
+               # the enqueueing thread's CPU time per step (its own work) beside the wall time it spent in the loop (which includes standing
+               # behind full launch queues): host-bound would be host_enqueue_cpu_ms_per_step ~ ms_per_step
+               "host_enqueue_cpu_ms_per_step": round(c_host / args.steps * 1e3, 3), "host_enqueue_wall_ms_per_step": round(t_host / args.steps * 1e3, 3),
+               "device_allocs_in_timed_region": a_timed1[0] - a_timed0[0]}
         if head_rows != B * T:
             # SURVEY 8d counts the LM head on all T text positions; the row-sparse head runs it (forward + both gradient GEMMs) on the
             # rows that carry a label -- `mfma_frac_whole_step` is priced on the flops actually executed

@@ -39,7 +39,9 @@ enum {
   MAFED_EPI_GELU = 1,     /* C = gelu_erf(acc + bias); aux (if non-NULL) receives the pre-activation acc + bias */
   MAFED_EPI_GELU_BWD = 2, /* C = (acc) * gelu_erf'(aux) ; aux = saved pre-activation, same dtype as C */
   MAFED_EPI_QUICK_GELU = 3, /* C = x * sigmoid(1.702 x), x = acc + bias: MLP activation of the frozen CLIP vision tower (clip:338-350) */
-  MAFED_EPI_RES1_BF16 = 0x100 /* flag, OR-ed in: res1 points at bf16 data (the attention branch output under bf16 autocast) */
+  MAFED_EPI_RES1_BF16 = 0x100, /* flag, OR-ed in: res1 points at bf16 data (the attention branch output under bf16 autocast) */
+  MAFED_EPI_NO_PERSISTENT = 0x200 /* flag, OR-ed in: THIS call keeps off the one-block-per-CU persistent kernels (a product that runs beside a
+                                     long-resident kernel of another stream, e.g. a collective); per call, no process-wide state */
 };
 
 int mafed_version(void);
@@ -261,11 +263,29 @@ int mafed_adamw_step_zero_grad(float* p, float* g, float* m, float* v, int64_t n
                                float eps, float weight_decay, int step, const float* clip_scale_dev, float grad_mul, void* p_bf16,
                                void* stream);
 
+/* General form: zeroes only the first `zero_n` elements of g (0 = none, n = all of it = mafed_adamw_step_zero_grad).  For the chunk of one
+ * decoder layer -- [LayerNorm weights | the four weight matrices] -- the host passes the LayerNorm part: their gradients are accumulated
+ * (+=) by the LayerNorm backward and need a zeroed buffer, the matrices' gradients are OVERWRITTEN by the first micro-batch's weight-
+ * gradient GEMMs of the next window (beta = 0), so zero-writing them (1.2 GB per step at 410M) and re-reading them in those GEMMs'
+ * epilogues is skipped.  Replaces optimizer.zero_grad() + AdamW.step (mafed/optim/adamw.py:50-113) for that chunk. */
+int mafed_adamw_step_partial_zero(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, const float* clip_scale_dev, float grad_mul, void* p_bf16,
+                                  int64_t zero_n, void* stream);
+
 /* Device-resident schedule (mafed/optim/sched.py:34-48 + the bias corrections of adamw.py:94-97): state_dev[0] = number of
  * optimiser steps taken so far; increments it to t and writes hyper3_dev = {base_lr * lambda(t-1), 1-b1^t, sqrt(1-b2^t)}
  * (double precision inside) for mafed_adamw_step(step = 0).  total_steps <= 0 means a constant learning rate. */
 int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1, double beta2,
                         float* hyper3_dev, void* stream);
+
+/* Guard of an optimiser step against a non-finite gradient (what a GradScaler does on the device): the gradient-norm kernels write the
+ * clip scale out2[1] = -1 when the global norm is NaN / infinite (e.g. the poisoned loss of the row-sparse head's overflow flag);
+ * mafed_adamw_step* given such a clip_dev leaves p, m, v and the bf16 shadow untouched (the zero_grad form still zeroes g),
+ * mafed_gradnorm_finish_advance does not advance the step counter, and this form of mafed_optim_advance does not either when
+ * clip_dev[1] < 0 (clip_dev may be NULL = unguarded).  The host sees the skipped step as a non-finite out2[0] / norm_log at its next
+ * natural synchronisation.  Reference behaviour (mafed/optim/adamw.py:86-111 applied to NaN gradients) would corrupt every parameter. */
+int mafed_optim_advance_guarded(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1, double beta2,
+                                float* hyper3_dev, const float* clip_dev, void* stream);
 
 /* mafed_gradnorm_finish followed by mafed_optim_advance as ONE launch (both are single-thread tails on the optimiser step's critical
  * path); norm_log (or NULL) additionally receives the norm -- a slot the caller owns, e.g. for the step's log record, so that no
@@ -321,6 +341,12 @@ const char* mafed_prof_tag_name(int tag);
  * 10 + c = force LDS-DMA tile configuration c; 100 = automatic split-K for accumulate-only outputs, 101 = no split-K,
  * 100 + n = force n K-splits where legal */
 int mafed_gemm_set_variant(int variant);
+/* 720 = the persistent kernels walk their tiles in the static order (tile = round x grid + slot), 721 = ticketed order (default): a
+ * block's first tile is static, every further one is drawn from a per-XCD queue, so a launch tolerates CUs held by other streams' kernels.
+ * mafed_gemm_get_variant reads the hooks back (which = 0: the tile-configuration variant, 7: the persistent-kernel mode 700 / 701 /
+ * 710 + c, 72: 720 / 721, 73: launches that ran in ticketed order so far), so that a caller that changes one for a measurement can
+ * restore what was set before */
+int mafed_gemm_get_variant(int which);
 /* 700 = never take the persistent ping-pong kernel, 701 = automatic (default), 710 + c = force its tile configuration c
  * (0: 144x256 tiles, 1: 128x256 tiles, 2: 256x256 tiles) wherever the shape tiles it.  mafed_gemm_pp_launches(): launches that took that kernel so far
  * (tests assert that a forced configuration really ran). */
@@ -336,6 +362,11 @@ int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, int D, int r
 /* Tuning helper (not on the product path): occupies `blocks` CUs with one 512-thread block each (`lds_bytes` of LDS) for ~`cycles` shader
  * clocks -- a stand-in for a long-running collective kernel when measuring GEMMs with part of the chip taken (tools/contention_bench.py). */
 int mafed_tune_occupy(int blocks, int lds_bytes, long long cycles, void* stream);
+
+/* Tuning helper (not on the product path): `blocks` workgroups of `threads` threads stream `n_bytes` of `src` with 16-byte accesses, `unroll`
+ * (2 / 4 / 8) loads in flight per thread; mode 0 reads, 1 copies to dst, 2 = four read + four written streams of n_bytes / 4 (AdamW-shaped).
+ * Measures what a FEW CUs stream from HBM while the rest of the chip does something else (tools/stream_cu_bench.py). */
+int mafed_tune_stream(const void* src, void* dst, long long n_bytes, int blocks, int threads, int unroll, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MAFED_HIP_LIB") or os.path.join(_HERE, "libmafed_hip.
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QUICK_GELU = 0, 1, 2, 3
 EPI_RES1_BF16 = 0x100
+EPI_NO_PERSISTENT = 0x200
 
 _p, _i, _l, _f, _z, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
@@ -25,6 +26,7 @@ SIGNATURES = {
     "mafed_gemm_colsum": (_i, [_i, _i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _l, _i, _p, _i, _p, _p, _p, _f, _p, _p]),
     "mafed_gemm_grouped": (_i, [_i, _i, _i, _i, _p, _i, _p]),
     "mafed_gemm_set_variant": (_i, [_i]),
+    "mafed_gemm_get_variant": (_i, [_i]),
     "mafed_gemm_pp_launches": (_i, []),
     "mafed_attn_decode": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "mafed_ewc_workspace_bytes": (_z, [_l]),
@@ -59,9 +61,12 @@ SIGNATURES = {
     "mafed_gradnorm_finish": (_i, [_p, _i, _f, _p, _p]),
     "mafed_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
     "mafed_adamw_step_zero_grad": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
+    "mafed_adamw_step_partial_zero": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _l, _p]),
     "mafed_distill_combine": (_i, [_p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p]),
     "mafed_optim_advance": (_i, [_p, _d, _l, _l, _d, _d, _p, _p]),
+    "mafed_optim_advance_guarded": (_i, [_p, _d, _l, _l, _d, _d, _p, _p, _p]),
     "mafed_tune_occupy": (_i, [_i, _i, C.c_longlong, _p]),
+    "mafed_tune_stream": (_i, [_p, _p, C.c_longlong, _i, _i, _i, _i, _p]),
     "mafed_gradnorm_finish_advance": (_i, [_p, _i, _f, _p, _p, _p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_pad_text_rows": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),

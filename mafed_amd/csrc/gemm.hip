@@ -644,7 +644,14 @@ static int g_gemm_pp_force = -1;
 static int g_gemm_pp_launches = 0;   // test hook: how many launches took the ping-pong kernel
 extern "C" int mafed_gemm_pp_launches(void) { return g_gemm_pp_launches; }
 namespace mafed { extern int g_skinny_ns, g_skinny_wide; }
+extern "C" int mafed_gemm_get_variant(int which) {   // which: 0 = tile-configuration variant, 7 = persistent-kernel mode (700 / 701 / 710 + c)
+  if (which == 7) return g_gemm_pp_force >= 0 ? 710 + g_gemm_pp_force : (g_gemm_pp ? 701 : 700);
+  if (which == 72) return 720 + gemm_pp_ticket_mode();
+  if (which == 73) return gemm_pp_ticket_launches();
+  return g_gemm_variant;
+}
 extern "C" int mafed_gemm_set_variant(int v) {
+  if (v == 720 || v == 721) { gemm_pp_set_ticket_mode(v - 720); return MAFED_OK; }   // persistent kernels: static / ticketed tile order
   if (v >= 700 && v < 800) { g_gemm_pp = v == 700 ? 0 : 1; g_gemm_pp_force = v >= 710 ? v - 710 : -1; return MAFED_OK; }
   if (v >= 600) { g_skinny_wide = v == 699 ? -1 : v - 600; return MAFED_OK; }
   if (v >= 500) { g_skinny_ns = v - 500; return MAFED_OK; }
@@ -701,6 +708,7 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
                                   void* stream) {
   MAFED_CHECK_ARG(problems && n >= 1, "gemm_grouped: no problems");
   bool one = in_dtype == MAFED_BF16 && n <= PP_MAXP && ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0);
+  for (int i = 0; one && i < n; ++i) one = !(problems[i].epilogue & MAFED_EPI_NO_PERSISTENT);   // per-call opt-out (mafed_hip.h)
   const bool a_ks = transA != 0, b_ks = transB == 0;
   PPProblem pr[PP_MAXP];
   int64_t Ms[PP_MAXP], Ns[PP_MAXP], Ks[PP_MAXP], ldas[PP_MAXP], ldbs[PP_MAXP];
@@ -708,7 +716,7 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
   for (int i = 0; one && i < n; ++i) {
     const mafed_gemm_problem& q = problems[i];
     const int res1_bf16 = (q.epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
-    GemmEpi epi{q.bias, q.epilogue & ~MAFED_EPI_RES1_BF16, q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
+    GemmEpi epi{q.bias, q.epilogue & ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT), q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
     one = q.A && q.B && q.C && q.M > 0 && (c_dtype == MAFED_F32 || q.beta == 0.f) && !(q.colsum && q.beta != 0.f) &&
           pp_fill_problem(pr[i], a_ks, b_ks, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, epi, q.colsum);
     Ms[i] = q.M; Ns[i] = q.N; Ks[i] = q.K; ldas[i] = q.lda; ldbs[i] = q.ldb;
@@ -743,7 +751,8 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
                   (long long)N, (long long)ldc);
   MAFED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
   const int res1_bf16 = (epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
-  epilogue &= ~MAFED_EPI_RES1_BF16;
+  const bool no_persistent = (epilogue & MAFED_EPI_NO_PERSISTENT) != 0;   // this call only: stay off the one-block-per-CU kernels
+  epilogue &= ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT);
   MAFED_CHECK_ARG(epilogue >= MAFED_EPI_NONE && epilogue <= MAFED_EPI_QUICK_GELU, "gemm: unknown epilogue %d", epilogue);
   MAFED_CHECK_ARG(epilogue != MAFED_EPI_GELU_BWD || aux, "gemm: GELU_BWD epilogue needs aux");
   MAFED_CHECK_ARG(beta == 0.f || c_dtype == MAFED_F32, "gemm: beta != 0 requires an fp32 C");
@@ -780,7 +789,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
     return MAFED_OK;
   }
   // persistent ping-pong kernel (gemm_pp.hip): tile-aligned shapes whose tile count fills the 256 CUs in whole rounds
-  if ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0) {
+  if (!no_persistent && ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0)) {
     PPProblem pr;
     if (pp_fill_problem(pr, a_ks, b_ks, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, epi, colsum)) {
       double fill = 0.0;

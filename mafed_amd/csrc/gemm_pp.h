@@ -5,7 +5,8 @@
 
 namespace mafed {
 
-constexpr int PP_MAXP = 16;  // problems per grouped launch (kernarg: 16 + 16 x 120 bytes)
+constexpr int PP_MAXP = 16;  // problems per grouped launch (kernarg: 32 + 16 x 120 bytes)
+constexpr int PP_TICKET_STRIDE = 16;   // dwords between the queue heads of a slot (one 64-byte line each: atomics on different heads do not share a line)
 
 // One C = op(A).op(B) problem of a (possibly grouped) persistent launch.  All problems of a launch share the operand
 // layouts (A_KS / B_KS), the output type and the tile configuration; shapes, leading dimensions and epilogues are their own.
@@ -30,6 +31,10 @@ struct PPProblem {
 
 struct PPArgs {
   int nprobs, ntiles, group_m, pad_;
+  // dynamic tile order (gemm_pp.hip "ticketed order"): eight per-XCD queue heads of THIS launch (16 dwords apart; NULL = static order) and the
+  // heads of the stream's other slot, which block 0 clears for the next ticketed launch on the same stream
+  unsigned* tickets;
+  unsigned* tickets_clear;
   PPProblem p[PP_MAXP];
 };
 
@@ -43,5 +48,12 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t
 // launches `n` problems (same layouts / output type / configuration) as ONE persistent grid
 int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,
                    const int64_t* Ks, hipStream_t st);
+
+// CUs of the current device (grid of the persistent kernels, the dispatcher's fill estimate)
+int gemm_pp_num_cus();
+// ticketed tile order on (default) / off (mafed_gemm_set_variant 721 / 720)
+void gemm_pp_set_ticket_mode(int on);
+int gemm_pp_ticket_mode();
+int gemm_pp_ticket_launches();
 
 }  // namespace mafed

@@ -29,8 +29,17 @@
 //     registers + double-buffered fragments) were built and spilled 28 - 217 registers: a spilled register anywhere puts a
 //     vmcnt(0) for its scratch reload into the loop, so they are not instantiated.
 //   * grouped launches: up to 16 problems (same layouts / output type) share one grid; the tile space is their concatenation.
+//   * ticketed tile order (round 4): a block's FIRST tile is static (tile id = its XCD-remapped slot, no latency at kernel start); every
+//     further tile is drawn from one of eight queues -- queue x = the tiles the static schedule would give the 32 blocks with
+//     blockIdx % 8 == x in rounds 1, 2, ... (same L2 patches), one returning atomic per tile on the queue's head.  A block that starts
+//     late (its CU was held by another stream's kernel) or runs slowly simply draws fewer tiles; when its queue is empty it exits and the
+//     CU is free for the late ones' static tiles.  The static schedule made every launch 1.6 - 1.8x as long with 8 CUs taken
+//     (profiles/r03_contention.txt).  The atomic is issued by one lane in front of the epilogue and its value parked in LDS behind it
+//     (compiler-counted, the only wait is the epilogue's own); the DMA stream reads it when it wraps to the next tile, one tile later,
+//     so a block always holds one claimed tile beyond the one it computes.
 //   * problem fields live in SGPRs and are re-read from the kernarg table only when the problem changes (a scalar load is a ~1 us
 //     round trip; a chain of them in front of every tile cost a K = 1024 tile a quarter of its time).
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_pp.h"
@@ -74,12 +83,14 @@ __device__ __forceinline__ int pp_f2(int k) { return ((k >> 1) & 1) | (((k >> 3)
 // capped build gained nothing, so the default stays uncapped.  (amdgpu_num_vgpr counts half-registers of the
 // unified VGPR + AGPR file on gfx950: N caps the kernel at 2 N.)
 #ifndef PP_VGPR_CAP
-#define PP_VGPR_CAP 256
+#define PP_VGPR_CAP 252   // v252 - v255 belong to the ticket statements (tk_issue / tk_park below), never to the compiler
 #endif
+// (the weight-gradient instantiation -- both operands reduction-major -- needs every register: it draws its tickets synchronously, below,
+//  and is the kernel gemm_pp_kernel_w without the cap; amdgpu_num_vgpr takes a literal, hence two kernels around one body)
 
 // MT x NT fragments of 16 x 16 per wave (wave tile MT*16 x NT*16, block tile MT*16 x 8*NT*16), NPH phases per K-tile, NSTG stages.
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2))) void gemm_pp_kernel(PPArgs args_by_value) {
+__device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
   constexpr int TM = MT * 16, TN = 8 * NT * 16;
   constexpr int MTP = MT / NPH;                 // A row fragments per phase
   static_assert(MT % NPH == 0 && TN == 256 && NT == 2, "1 x 8 waves of MT*16 x 32, 256 columns");
@@ -183,6 +194,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
 
   // ---- tile space ---------------------------------------------------------------------------------------------------------
   const int G = (int)gridDim.x, ntiles = args->ntiles;
+  // ticketed order (header comment): heads of this launch's eight queues, or NULL = static order (host: single round, capture, no slot)
+  unsigned* const tk_heads = args->tickets;
+  const bool dyn = tk_heads != nullptr;
+  const int tk_per = G >> 3, tk_q = (int)blockIdx.x & 7;
+  int* const tk_lds = reinterpret_cast<int*>(smem + NSTG * STAGE + 2048 + PP_TRACE_BYTES);
+  const uint32_t tk_lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)tk_lds;
+  constexpr int TKW = 7;            // the wave whose lane 0 draws the tickets
+  const bool tk_wave = dyn && wave == TKW;
+  // The draw is ONE inline-asm returning atomic by lane 0 (EXEC narrowed inside the statement), invisible to hipcc's wait-count pass: a
+  // compiler-visible atomic is waited for with vmcnt(0) where its result register is next written -- an MFMA destination inside the K
+  // loop (measured in the ISA) -- which drains the DMA ring every K-tile.  Its value lands in `tk_raw` some 0.3 - 1.3 us later
+  // (MI355X_MICROARCH "dequeue").  Where it is issued and where it is read follow from the wave's in-order VMEM queue:
+  //   * issued inside the epilogue, behind its bias / operand fetches and in front of its C stores: the K loop's first wait after an
+  //     epilogue tolerates the NST stores and nothing older, so it also covers the atomic -- by then the epilogue's arithmetic and the
+  //     first phase have passed; no wait in the schedule changes;
+  //   * parked in LDS (a plain store of lane 0) one interval after that wait, read by every wave when its DMA stream wraps to the next
+  //     tile.  Between the asm and the park nothing may touch the register: tools/pp_ticket_audit.py checks the ISA of every build.
+  // The landing register is v255, OUTSIDE what hipcc may allocate: the kernel's register cap (amdgpu_num_vgpr, below 256) leaves v252 - v255
+  // to these two statements, so no copy, spill or re-use by the compiler can touch the register while the atomic is in flight.
+  // TK_SYNC (the weight-gradient kernel: 144 K-tiles per tile, and no register to give away): the same atomic with its own vmcnt(0) in
+  // the statement, parked at once -- a microsecond per 160-us tile.
+  constexpr bool TK_SYNC = A_KS && B_KS;
+  auto tk_issue = [&]() {
+    unsigned long long sav;
+    const unsigned off = (unsigned)(tk_q * PP_TICKET_STRIDE * 4), one = 1u;
+    if constexpr (!TK_SYNC) {
+      // (s_nop 4: the queue base may come straight from a v_readlane of a spilled SGPR -- VALU-written SGPR -> VMEM address, 5 wait states)
+      asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
+                   : "=&s"(sav)
+                   : "v"(off), "v"(one), "s"(tk_heads)
+                   : "memory", "v255");
+    } else {
+      int v;
+      asm volatile("s_nop 4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %1"
+                   : "=&v"(v), "=&s"(sav)
+                   : "v"(off), "v"(one), "s"(tk_heads)
+                   : "memory");
+      if (lane == 0) *tk_lds = v;
+    }
+  };
+  auto tk_park = [&]() {   // lane 0's value (landed: see above) -> LDS; a compiler-visible store, so that hipcc's lgkmcnt counts include it
+    if constexpr (!TK_SYNC) {
+      int v;
+      asm volatile("v_mov_b32 %0, v255" : "=v"(v));
+      if (lane == 0) *tk_lds = v;
+    }
+  };
+  if (dyn && blockIdx.x == 0 && wave == 0 && lane < 8 && args->tickets_clear)
+    __hip_atomic_store(args->tickets_clear + lane * PP_TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tk_wave) tk_issue();   // the block's second tile: oldest operation of the wave, complete behind the prologue's wait
   int slot;
   {
     const int b = (int)blockIdx.x, q = G >> 3, r = G & 7, x = b & 7;   // bijective XCD remap (cdna_hip_programming T1)
@@ -225,6 +286,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
 
   // ---- DMA stream state: `pa`, `pb` point at the operand bytes of the stream's current K-tile ------------------------------------
   int d_id = slot, d_pi = 0, d_tm, d_tn, d_kt = 0;
+  bool has_next = false;   // the DMA stream's tile (decided when it wrapped) is a real tile of this block
   const char *pa, *pb;
   uint32_t a_step, b_step;
   auto dma_set_tile = [&](bool new_ld) {
@@ -241,8 +303,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
       pa += a_step;
       pb += b_step;
     } else {
-      d_id += G;
-      if (d_id >= ntiles) d_id = slot;
+      // next tile of this block: static order id + G, ticketed order the id parked in LDS behind the previous epilogue (the prologue)
+      int nid = d_id + G;
+      if (dyn) {   // (one asm statement = read + its own wait: a volatile LDS load makes hipcc drain vmcnt(0) -- the DMA ring -- around it)
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(tk_lds_addr) : "memory");
+        const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(v), r = t / (unsigned)tk_per;   // t-th draw of queue tk_q
+        nid = r >= 0x10000u ? 0x7fffffff : (int)((1u + r) * (unsigned)G + (unsigned)(tk_q * tk_per) + (t - r * (unsigned)tk_per));
+      }
+      has_next = (unsigned)nid < (unsigned)ntiles;   // (unsigned: whatever the ticket word holds, a tile id outside the launch is never decoded)
+      d_id = has_next ? nid : slot;   // (no further tile: the stream idles on the block's first tile, its pieces are never read)
       const bool changed = decode(d_id, d_pi, d_tm, d_tn);
       dma_set_tile(changed);
     }
@@ -392,6 +462,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
   auto seg_load = [&](auto stage_c, int p, int set, int post, bool last) {
     constexpr int S = decltype(stage_c)::value;
     const int so_c = NSTG == 2 ? S * STAGE : st0, so_n = NSTG == 2 ? (S ^ 1) * STAGE : st1;
+    // ticket park: the interval after the first wait behind an epilogue (slot 1 with three phases, slot 0 with two), in front of this
+    // interval's fragment reads (the counted lgkmcnt waits below cover "all but the youngest reads")
+    if (post == 1 && p == (NPH == 3 ? 2 : 1) && tk_wave) { tk_park(); __builtin_amdgcn_sched_barrier(0); }
     if (p + 1 < NPH) {
       read_a(smem + so_c, p + 1, fa[set ^ 1]);
     } else if (!last) {
@@ -456,8 +529,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
 
   // ---- epilogue (gemm_pp_epilogue.h): straight from the accumulators, 64-byte row segments per store instruction -----------------
   auto epilogue = [&](int tm, int tn) {
+    const bool draw = tk_wave && has_next;   // (wave-uniform: the ticket wave of a block that has a further tile)
     PPEpilogue<MT, NT, CT, false, (A_KS && B_KS)>::run(acc, cq, (int64_t)tm * TM + li, (int64_t)tn * TN + wave * NT * 16, lane,
-                                reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64);
+                                reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64, [&]() { if (draw) tk_issue(); });
   };
 
   // ---- main ----------------------------------------------------------------------------------------------------------------
@@ -482,6 +556,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
     dma_group(2 * STAGE, 0);
     pp_wait_vmcnt<9>();
   }
+  if (tk_wave) tk_park();   // (landed: the atomic is older than every piece the wait above covers)
   __builtin_amdgcn_s_barrier();
   abl_dma_on = false;
   bool first = true;
@@ -507,11 +582,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
       }
     }
     trace_event(1);
-    if (!(MAFED_PP_ABL == 5 || MAFED_PP_ABL == 7) || id + G >= ntiles) epilogue(tm, tn);
+    // (ticket for the tile after next: drawn inside the epilogue, parked in the first K-tile of the next tile)
+    if (!(MAFED_PP_ABL == 5 || MAFED_PP_ABL == 7) || !has_next) epilogue(tm, tn);
+    else if (tk_wave) tk_issue();
     trace_event(2);
     first = false;
-    id += G;
-    if (id >= ntiles) break;
+    if (!has_next) break;
+    id = d_id;
     // the DMA stream switched to this tile K-tiles ago: its coordinates are already decoded
     if (d_pi != pi) load_cq(d_pi);
     pi = d_pi; tm = d_tm; tn = d_tn;
@@ -529,20 +606,109 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2
 #endif
 }
 
+template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2))) void gemm_pp_kernel(PPArgs args_by_value) {
+  static_assert(!(A_KS && B_KS), "the weight-gradient layout runs as gemm_pp_kernel_w");
+  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT>(args_by_value);
+}
+template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void gemm_pp_kernel_w(PPArgs args_by_value) {
+  static_assert(A_KS && B_KS, "synchronous tickets, no register cap: the weight-gradient layout only");
+  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT>(args_by_value);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------------------
+// ---- ticket slots ------------------------------------------------------------------------------------------------------------------
+// Two slots of eight queue heads per stream, used alternately by that stream's ticketed launches: launches of one stream run in order,
+// so when launch n starts launch n - 1 has finished with the other slot -- block 0 of launch n clears it for launch n + 1.  No reset
+// launch, no host-side count of the draws, nothing shared between streams.  The memory is a zero-initialised __device__ array of this
+// code object (the library never allocates).
+constexpr int PP_TK_STREAMS = 64, PP_TK_SLOT = 8 * PP_TICKET_STRIDE;
+__device__ unsigned g_pp_ticket_mem[PP_TK_STREAMS * 2 * PP_TK_SLOT];
+namespace {
+std::mutex g_tk_mu;   // launches come from the caller's thread and from autograd's backward thread
+struct TkStream { hipStream_t st; int dev; int parity; };
+TkStream g_tk_streams[PP_TK_STREAMS];
+int g_tk_n = 0;
+unsigned* g_tk_base[16] = {};
+int g_tk_mode = 1;     // mafed_gemm_set_variant(720) = static order everywhere, 721 = ticketed (default)
+int g_tk_launches = 0; // test hook: launches that ran in ticketed order
+int g_num_cus = 0;
+}  // namespace
+void gemm_pp_set_ticket_mode(int on) { g_tk_mode = on ? 1 : 0; }
+int gemm_pp_ticket_mode() { return g_tk_mode; }
+int gemm_pp_ticket_launches() { return g_tk_launches; }
+
+// CUs of the current device (the persistent grid and the dispatcher's fill estimate; 256 on MI355X, fewer in a partition mode)
+int gemm_pp_num_cus() {
+  if (g_num_cus > 0) return g_num_cus;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) g_num_cus = n;
+  else { (void)hipGetLastError(); return 256; }   // (no device: the CPU-side checks of the dispatcher)
+  return g_num_cus;
+}
+
+// Slot pointers for a ticketed launch on `st` (false: table full / capture in progress / no device symbol -> static order).  Caller holds g_tk_mu.
+static bool tk_acquire(hipStream_t st, unsigned** cur, unsigned** other, int* entry) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (cs != hipStreamCaptureStatusNone) return false;   // a captured launch would replay with the same slot: static order inside graphs
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return false; }
+  if (!g_tk_base[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_pp_ticket_mem)) != hipSuccess || !ptr) { (void)hipGetLastError(); return false; }
+    g_tk_base[dev] = reinterpret_cast<unsigned*>(ptr);
+  }
+  int e = -1, same_dev = 0;
+  for (int i = 0; i < g_tk_n; ++i) {
+    if (g_tk_streams[i].dev != dev) continue;
+    if (g_tk_streams[i].st == st) { e = i; break; }
+    ++same_dev;
+  }
+  if (e < 0) {
+    if (g_tk_n >= PP_TK_STREAMS) return false;
+    (void)same_dev;
+    e = g_tk_n++;
+    g_tk_streams[e] = TkStream{st, dev, 0};
+  }
+  unsigned* base = g_tk_base[dev] + (size_t)e * 2 * PP_TK_SLOT;
+  *cur = base + g_tk_streams[e].parity * PP_TK_SLOT;
+  *other = base + (g_tk_streams[e].parity ^ 1) * PP_TK_SLOT;
+  *entry = e;
+  return true;
+}
+
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
-static int pp_launch_t(const PPArgs& a, double flops, hipStream_t st) {
+static int pp_launch_t(const PPArgs& a_in, double flops, hipStream_t st) {
   constexpr int TM = MT * 16, TN = 8 * NT * 16;
-  constexpr int LDS = NSTG * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES;
-  auto kfn = gemm_pp_kernel<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
+  constexpr int LDS = NSTG * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES + 64;   // stages | epilogue strips | (trace) | ticket word
+  void (*kfn)(PPArgs);
+  if constexpr (A_KS && B_KS) kfn = gemm_pp_kernel_w<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
+  else kfn = gemm_pp_kernel<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  const int ncu = gemm_pp_num_cus();
+  const int grid = a_in.ntiles < ncu ? a_in.ntiles : ncu;
+  PPArgs a = a_in;
+  a.tickets = a.tickets_clear = nullptr;
+  if (g_tk_mode && a.ntiles > grid && grid % 8 == 0) {
+    // more than one round: ticketed order.  Slot choice, parity flip and launch are one critical section, so that the alternation of
+    // the two slots follows the stream's launch order whichever host thread launches.
+    std::lock_guard<std::mutex> lk(g_tk_mu);
+    int e = -1;
+    if (tk_acquire(st, &a.tickets, &a.tickets_clear, &e)) {
+      launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(512), LDS, st, a);
+      if (hipPeekAtLastError() == hipSuccess) { g_tk_streams[e].parity ^= 1; ++g_tk_launches; }   // (a refused launch never ran: the slot stays the stream's current one)
+      return MAFED_OK;
+    }
+    a.tickets = a.tickets_clear = nullptr;
+  }
   launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(512), LDS, st, a);
   return MAFED_OK;
 }
@@ -588,8 +754,9 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t
       tiles += (Ms[i] / TM) * (Ns[i] / TN);
     }
     if (!ok) continue;
-    const int64_t rounds = (tiles + 255) / 256;
-    const double fill = (double)tiles / (double)(rounds * 256);
+    const int64_t ncu = gemm_pp_num_cus();
+    const int64_t rounds = (tiles + ncu - 1) / ncu;
+    const double fill = (double)tiles / (double)(rounds * ncu);
     // 256 x 256 tiles run their k loop ~15 % faster per flop (half the LDS-DMA bytes per MFMA); at equal cost the 8-wave kernel wins
     const double score = fill * (cfg == PP_256x256 ? 1.15 : 1.0);
     if (score > best_score) { best_score = score; best = cfg; best_fill = fill; }
@@ -607,6 +774,7 @@ int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPP
   PPArgs a;
   a.nprobs = n;
   a.pad_ = 0;
+  a.tickets = a.tickets_clear = nullptr;
   int tiles = 0;
   double flops = 0.0;
   int min_tn = 1 << 30;

@@ -50,8 +50,10 @@ struct PPEpilogue {
   static constexpr int GSTEP = PAIR ? 32 : 16;
   static constexpr int NST = PAIR ? MT * NPAIR : MT * NT;   // C stores per wave per tile: lower bound of the epilogue's VMEM operations
 
-  template <int MODE, int HSRC, int FSRC>
-  static __device__ __forceinline__ void fast(f32x4 (&acc)[NT][MT], const PPEpiProb& cq, int64_t row0, int64_t colw, int lane, float* scr) {
+  // `hook`: called once, behind the epilogue's bias / first operand fetches and in front of its first C store (gemm_pp.hip issues the
+  // ticket atomic there: older than the stores, younger than the fetches this wave is about to wait for)
+  template <int MODE, int HSRC, int FSRC, typename Hook>
+  static __device__ __forceinline__ void fast(f32x4 (&acc)[NT][MT], const PPEpiProb& cq, int64_t row0, int64_t colw, int lane, float* scr, Hook&& hook) {
     const int li = lane & 15, q4 = lane >> 4;
     CT* __restrict__ C = reinterpret_cast<CT*>(cq.C);
     const float* __restrict__ bias = cq.bias;
@@ -97,6 +99,7 @@ struct PPEpilogue {
     Pre pre[NI];
 #pragma unroll
     for (int i = 0; i < PD; ++i) fetch(i, pre[i]);
+    hook();
     float cs[GW];
 #pragma unroll
     for (int idx = 0; idx < NI; ++idx) {
@@ -210,21 +213,26 @@ struct PPEpilogue {
       }
   }
 
+  struct NoHook { __device__ __forceinline__ void operator()() const {} };
   static __device__ __forceinline__ void run(f32x4 (&acc)[NT][MT], const PPEpiProb& cq, int64_t row0, int64_t colw, int lane, float* scr) {
+    run(acc, cq, row0, colw, lane, scr, NoHook{});
+  }
+  template <typename Hook>
+  static __device__ __forceinline__ void run(f32x4 (&acc)[NT][MT], const PPEpiProb& cq, int64_t row0, int64_t colw, int lane, float* scr, Hook&& hook) {
     const int mode = cq.mode;
     const bool r1 = cq.res1 != nullptr, r1h = r1 && cq.res1_bf16, r2 = cq.res2 != nullptr;
     const bool bt = cq.beta != 0.f;
     if constexpr (PLAIN_ONLY) {
-      if (!PAIR && bt) fast<MAFED_EPI_NONE, 0, (PAIR ? 0 : 2)>(acc, cq, row0, colw, lane, scr);
-      else fast<MAFED_EPI_NONE, 0, 0>(acc, cq, row0, colw, lane, scr);
+      if (!PAIR && bt) fast<MAFED_EPI_NONE, 0, (PAIR ? 0 : 2)>(acc, cq, row0, colw, lane, scr, hook);
+      else fast<MAFED_EPI_NONE, 0, 0>(acc, cq, row0, colw, lane, scr, hook);
       return;
     }
-    if (mode == MAFED_EPI_NONE && !r1 && !r2 && !bt) fast<MAFED_EPI_NONE, 0, 0>(acc, cq, row0, colw, lane, scr);
-    else if (mode == MAFED_EPI_GELU && !r1 && !r2 && !bt) fast<MAFED_EPI_GELU, 0, 0>(acc, cq, row0, colw, lane, scr);
-    else if (PAIR && mode == MAFED_EPI_GELU_BWD && !r1 && !r2 && !bt) fast<(PAIR ? MAFED_EPI_GELU_BWD : MAFED_EPI_NONE), (PAIR ? 1 : 0), 0>(acc, cq, row0, colw, lane, scr);
-    else if (mode == MAFED_EPI_NONE && r1h && r2 && !bt) fast<MAFED_EPI_NONE, 2, 1>(acc, cq, row0, colw, lane, scr);
-    else if (!PAIR && mode == MAFED_EPI_NONE && !r1 && !r2 && bt) fast<MAFED_EPI_NONE, 0, (PAIR ? 0 : 2)>(acc, cq, row0, colw, lane, scr);
-    else generic(acc, cq, row0, colw, lane);   // any other combination: the in-place operand loads of gemm_epilogue.h (no prefetch, no fused column sums)
+    if (mode == MAFED_EPI_NONE && !r1 && !r2 && !bt) fast<MAFED_EPI_NONE, 0, 0>(acc, cq, row0, colw, lane, scr, hook);
+    else if (mode == MAFED_EPI_GELU && !r1 && !r2 && !bt) fast<MAFED_EPI_GELU, 0, 0>(acc, cq, row0, colw, lane, scr, hook);
+    else if (PAIR && mode == MAFED_EPI_GELU_BWD && !r1 && !r2 && !bt) fast<(PAIR ? MAFED_EPI_GELU_BWD : MAFED_EPI_NONE), (PAIR ? 1 : 0), 0>(acc, cq, row0, colw, lane, scr, hook);
+    else if (mode == MAFED_EPI_NONE && r1h && r2 && !bt) fast<MAFED_EPI_NONE, 2, 1>(acc, cq, row0, colw, lane, scr, hook);
+    else if (!PAIR && mode == MAFED_EPI_NONE && !r1 && !r2 && bt) fast<MAFED_EPI_NONE, 0, (PAIR ? 0 : 2)>(acc, cq, row0, colw, lane, scr, hook);
+    else { hook(); generic(acc, cq, row0, colw, lane); }   // any other combination: the in-place operand loads of gemm_epilogue.h (no prefetch, no fused column sums)
   }
 };
 

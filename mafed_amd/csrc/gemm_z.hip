@@ -344,7 +344,8 @@ static int z_launch_t(const PPArgs& a, double flops, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  const int ncu = gemm_pp_num_cus();
+  const int grid = a.ntiles < ncu ? a.ntiles : ncu;   // (static tile order: the ticketed order of gemm_pp.hip is not built into this kernel)
   launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(256), LDS, st, a);
   return MAFED_OK;
 }

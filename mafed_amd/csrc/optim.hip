@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __res
   if (threadIdx.x == 0) {
     const float norm = sqrtf(s);
     out2[0] = norm;
-    out2[1] = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+    // torch clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1); a non-finite norm marks the step as skipped (scale -1: the AdamW
+    // kernel then leaves parameters and optimiser state alone -- fminf(1, max_norm / NaN) would be 1 and NaN gradients would be applied)
+    out2[1] = isfinite(norm) ? fminf(1.0f, max_norm / (norm + 1e-6f)) : -1.0f;
   }
 }
 
@@ -57,17 +59,29 @@ template <bool SHADOW, bool ZERO_G = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float beta1,
                                                     float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    const float* __restrict__ clip_dev, float grad_mul, bf16_t* __restrict__ p_bf16) {
+                                                    const float* __restrict__ clip_dev, float grad_mul, bf16_t* __restrict__ p_bf16,
+                                                    int64_t zero_n) {
+  // ZERO_G: g[0 .. zero_n) is zeroed in the same pass (zero_n = n: the whole chunk; the layer chunks pass their LayerNorm part only)
+  const int64_t zero4 = zero_n / 4;
   const float lr = lr_dev[0];
   if (bc1 <= 0.f) {  // hyper-parameters of this step live in device memory (hipGraph replay): {lr, 1-b1^t, sqrt(1-b2^t)}
     bc1 = lr_dev[1];
     bc2_sqrt = lr_dev[2];
   }
-  const float gs = grad_mul * (clip_dev ? clip_dev[1] : 1.0f);
+  const float clip = clip_dev ? clip_dev[1] : 1.0f;
+  const bool skip = clip < 0.f;   // non-finite gradient norm (gradnorm_finish): no update, optimiser state untouched; g is still zeroed
+  const float gs = grad_mul * clip;
   const float step_size = lr * bc2_sqrt / bc1;
   const float decay = lr * wd;
   const int64_t n4 = n / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (skip) {
+    if (ZERO_G) {
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4 && i < zero4; i += stride) store4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+      if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4) && n4 * 4 + threadIdx.x < zero_n) g[n4 * 4 + threadIdx.x] = 0.f;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 pp = load4(p + i * 4), gg = load4(g + i * 4), mm = load4(m + i * 4), vv = load4(v + i * 4);
     float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
     store4(p + i * 4, pp); store4(m + i * 4, mm); store4(v + i * 4, vv);
     if (SHADOW) store4(p_bf16 + i * 4, pp);
-    if (ZERO_G) store4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));  // optimizer.zero_grad() of the next window, same pass
+    if (ZERO_G && i < zero4) store4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));  // optimizer.zero_grad() of the next window, same pass
   }
   if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
     const int64_t i = n4 * 4 + threadIdx.x;
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     if (wd > 0.f) x = x - decay * x;
     p[i] = x; m[i] = mk; v[i] = vk;
     if (SHADOW) p_bf16[i] = f32_to_bf16(x);
-    if (ZERO_G) g[i] = 0.f;
+    if (ZERO_G && i < zero_n) g[i] = 0.f;
   }
 }
 
@@ -120,8 +134,9 @@ __device__ __forceinline__ void optim_advance_body(long long* __restrict__ state
 }
 
 __global__ void optim_advance_kernel(long long* __restrict__ state, double base_lr, long long warmup, long long total, double b1,
-                                     double b2, float* __restrict__ hyper) {
+                                     double b2, float* __restrict__ hyper, const float* __restrict__ clip_dev) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (clip_dev && clip_dev[1] < 0.f) return;   // skipped step (non-finite gradient norm): the counter and the schedule stand still
   optim_advance_body(state, base_lr, warmup, total, b1, b2, hyper);
 }
 
@@ -147,9 +162,10 @@ __global__ __launch_bounds__(256) void gradnorm_finish_advance_kernel(const floa
   if (threadIdx.x == 0) {
     const float norm = sqrtf(s);
     out2[0] = norm;
-    out2[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+    const bool ok = isfinite(norm);
+    out2[1] = ok ? fminf(1.0f, max_norm / (norm + 1e-6f)) : -1.0f;
     if (norm_log) norm_log[0] = norm;
-    optim_advance_body(state, base_lr, warmup, total, b1, b2, hyper);
+    if (ok) optim_advance_body(state, base_lr, warmup, total, b1, b2, hyper);
   }
 }
 
@@ -161,7 +177,16 @@ extern "C" int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t w
                                    double beta2, float* hyper3_dev, void* stream) {
   MAFED_CHECK_ARG(state_dev && hyper3_dev, "optim_advance: null pointer");
   optim_advance_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>((long long*)state_dev, base_lr, (long long)warmup_steps,
-                                                                    (long long)total_steps, beta1, beta2, hyper3_dev);
+                                                                    (long long)total_steps, beta1, beta2, hyper3_dev, nullptr);
+  MAFED_CHECK_LAUNCH("optim_advance");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_optim_advance_guarded(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1,
+                                           double beta2, float* hyper3_dev, const float* clip_dev, void* stream) {
+  MAFED_CHECK_ARG(state_dev && hyper3_dev, "optim_advance: null pointer");
+  optim_advance_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>((long long*)state_dev, base_lr, (long long)warmup_steps,
+                                                                    (long long)total_steps, beta1, beta2, hyper3_dev, clip_dev);
   MAFED_CHECK_LAUNCH("optim_advance");
   return MAFED_OK;
 }
@@ -224,7 +249,9 @@ extern "C" int mafed_gradnorm_finish_advance(const float* partial, int n_partial
 }
 
 static int adamw_impl(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
-                      float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16, bool zero_g, void* stream) {
+                      float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16, int64_t zero_n, void* stream) {
+  MAFED_CHECK_ARG(zero_n >= 0 && zero_n <= n && (zero_n == n || zero_n % 4 == 0), "adamw_step: zero_n must be 0 .. n and a multiple of 4 (or n)");
+  const bool zero_g = zero_n > 0;
   MAFED_CHECK_ARG(p && g && m && v && lr_dev && n >= 0 && step >= 0, "adamw_step: bad arguments");
   MAFED_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step: buffers must be 16-byte aligned");
   MAFED_CHECK_ARG(!p_bf16 || ((uintptr_t)p_bf16 & 7) == 0, "adamw_step: p_bf16 must be 8-byte aligned");
@@ -237,10 +264,10 @@ static int adamw_impl(float* p, float* g, float* m, float* v, int64_t n, const f
   int64_t nb = cdiv(n / 4 + 1, 256);
   if (nb > 4096) nb = 4096;
   // algorithmic bytes: p, m, v read + written, g read (+ the bf16 shadow weight written, + the gradient zeroed) per parameter
-  const double bytes = (double)n * (28.0 + (p_bf16 ? 2.0 : 0.0) + (zero_g ? 4.0 : 0.0));
+  const double bytes = (double)n * (28.0 + (p_bf16 ? 2.0 : 0.0)) + (double)zero_n * 4.0;
 #define MAFED_ADAMW(SH, ZG)                                                                                                          \
   launch(K_ADAMW, bytes, adamw_kernel<SH, ZG>, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, \
-         (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16)
+         (float)bc1, (float)sqrt(bc2), clip_dev, grad_mul, (bf16_t*)p_bf16, zero_n)
   if (p_bf16 && zero_g) MAFED_ADAMW(true, true);
   else if (p_bf16) MAFED_ADAMW(true, false);
   else if (zero_g) MAFED_ADAMW(false, true);
@@ -253,11 +280,17 @@ static int adamw_impl(float* p, float* g, float* m, float* v, int64_t n, const f
 extern "C" int mafed_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
                                 float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
                                 void* stream) {
-  return adamw_impl(p, const_cast<float*>(g), m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, false, stream);
+  return adamw_impl(p, const_cast<float*>(g), m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, 0, stream);
 }
 
 extern "C" int mafed_adamw_step_zero_grad(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
                                           float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
                                           void* stream) {
-  return adamw_impl(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, true, stream);
+  return adamw_impl(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, n, stream);
+}
+
+extern "C" int mafed_adamw_step_partial_zero(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                                             float eps, float weight_decay, int step, const float* clip_dev, float grad_mul, void* p_bf16,
+                                             int64_t zero_n, void* stream) {
+  return adamw_impl(p, g, m, v, n, lr_dev, beta1, beta2, eps, weight_decay, step, clip_dev, grad_mul, p_bf16, zero_n, stream);
 }

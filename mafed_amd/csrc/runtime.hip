@@ -124,5 +124,56 @@ extern "C" int mafed_tune_occupy(int blocks, int lds_bytes, long long cycles, vo
   return MAFED_OK;
 }
 
+
+// Streaming probe (tools/stream_cu_bench.py): `blocks` workgroups of `threads` threads sweep `n_bytes` of `src` with 16-byte loads,
+// `unroll` independent loads in flight per thread (mode 0: read + fold, mode 1: copy to dst, mode 2: AdamW-shaped -- four read streams of
+// n_bytes / 4 each, four written).  Answers: what does ONE CU (or 8, 32, ...) stream from HBM when the rest of the chip does not?
+namespace mafed {
+template <int U>
+__global__ __launch_bounds__(1024) void stream_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n16, int mode,
+                                                            float* sink) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = 0.f;
+  if (mode == 2) {
+    const long long q = n16 / 4;
+    for (; i < q; i += stride) {
+      float4 a = src[i], b = src[q + i], c = src[2 * q + i], d = src[3 * q + i];
+      a.x += b.x * c.x + d.x; a.y += b.y * c.y + d.y; a.z += b.z * c.z + d.z; a.w += b.w * c.w + d.w;
+      dst[i] = a; dst[q + i] = b; dst[2 * q + i] = c; dst[3 * q + i] = d;
+    }
+  } else {
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (mode == 1) dst[i + u * stride] = v[u];
+        else acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      }
+    }
+    for (; i < n16; i += stride) {
+      const float4 v = src[i];
+      if (mode == 1) dst[i] = v;
+      else acc += (v.x + v.y) + (v.z + v.w);
+    }
+  }
+  if (acc == 1.2345e-30f && sink) sink[0] = acc;
+}
+}  // namespace mafed
+extern "C" int mafed_tune_stream(const void* src, void* dst, long long n_bytes, int blocks, int threads, int unroll, int mode, void* stream) {
+  using namespace mafed;
+  MAFED_CHECK_ARG(src && n_bytes >= 0 && n_bytes % 64 == 0 && blocks >= 1 && blocks <= 65536 && threads >= 64 && threads <= 1024 && threads % 64 == 0 &&
+                  mode >= 0 && mode <= 2 && (mode == 0 || dst), "tune_stream: bad arguments");
+  const long long n16 = n_bytes / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (unroll >= 8) stream_probe_kernel<8><<<dim3(blocks), dim3(threads), 0, st>>>((const float4*)src, (float4*)dst, n16, mode, nullptr);
+  else if (unroll >= 4) stream_probe_kernel<4><<<dim3(blocks), dim3(threads), 0, st>>>((const float4*)src, (float4*)dst, n16, mode, nullptr);
+  else stream_probe_kernel<2><<<dim3(blocks), dim3(threads), 0, st>>>((const float4*)src, (float4*)dst, n16, mode, nullptr);
+  MAFED_CHECK_LAUNCH("tune_stream");
+  return MAFED_OK;
+}
+
 extern "C" int mafed_version(void) { return 110; }
 extern "C" const char* mafed_last_error_string(void) { return mafed::g_err; }

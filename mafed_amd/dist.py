@@ -206,6 +206,28 @@ def broadcast_teacher(model, src: int = 0, process_group=None) -> None:
         model._shadow_dirty = True
 
 
+def reduce_validation_metrics(n_ex, val_loss, tot_score, process_group=None, device=None):
+    """Sum of the validation counters over the ranks, as the reference does at the end of its validation loops
+    (mafed/utils/eval_utils.py:135-137: ``dist.all_reduce(torch.tensor([n_ex, val_loss, tot_score]))``; the torchmetrics states of
+    ``VQAGenerativeAccuracy`` -- ``accuracy`` and ``total``, ``dist_reduce_fx="sum"``, eval_utils.py:89-90 -- reduce the same way).
+    Every rank calls it with its own partial sums and gets the global ones back as Python numbers; a single process returns its input.
+    One collective of three floats (fp64 on the wire: example counts beyond 2^24 stay exact)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) < 2:
+        return float(n_ex), float(val_loss), float(tot_score)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(process_group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(n_ex), float(val_loss), float(tot_score)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+    n, l, s = t.tolist()
+    return n, l, s
+
+
+def generative_accuracy(accuracy_sum, total, process_group=None, device=None) -> float:
+    """``VQAGenerativeAccuracy.compute()`` under data parallelism (eval_utils.py:84-107): sum(accuracy) / sum(total) over the ranks."""
+    n, _, s = reduce_validation_metrics(total, 0.0, accuracy_sum, process_group, device)
+    return s / n if n > 0 else float("nan")
+
+
 def init_from_env(backend: Optional[str] = None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* rendezvous as launched by torch.distributed.run."""
     import os

@@ -66,6 +66,16 @@ def global_token_counts(sums: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+_ZERO_SCALARS: Dict[str, torch.Tensor] = {}
+
+
+def _zero_scalar(device) -> torch.Tensor:
+    z = _ZERO_SCALARS.get(str(device))
+    if z is None:
+        z = _ZERO_SCALARS[str(device)] = torch.zeros((), device=device)
+    return z
+
+
 class _FusedDistillLossFn(torch.autograd.Function):
     """The whole MSE distillation term of the native model as ONE node: the per-layer masked sums (started layer by layer
     during the student forward, or computed here), then ``mafed_distill_combine`` -- masked means, modality weights, layer
@@ -100,8 +110,9 @@ class _FusedDistillLossFn(torch.autograd.Function):
         ctx.sv["inject"] = {layer: (ctx.teacher[k], scaled[k]) for k, layer in enumerate(ctx.layers)}
         ctx.sv["inject_cosine"] = ctx.cosine
         ctx.sv = None
-        # (the hook's "gradient" only makes the model's node run; its value is never read: no fill kernel for it)
-        return (torch.empty((), device=g.device),) + (None,) * (12 + len(ctx.layers))
+        # (the hook's "gradient" only makes the model's node run; its value is never read: a cached zero scalar -- no fill kernel per
+        #  step, and nothing uninitialised for anomaly detection or an accidental accumulation to pick up)
+        return (_zero_scalar(g.device),) + (None,) * (12 + len(ctx.layers))
 
 
 class _DistillClsFn(torch.autograd.Function):
@@ -367,6 +378,9 @@ class FeatureDistillation(CLStrategy):
         pm = self.past_model
         if pm is None or not hasattr(pm, "hidden_states_upto") or not hasattr(mem, "data") or len(mem) == 0:
             raise RuntimeError("teacher cache: needs the native teacher and a resident replay memory (HBMReplayBuffer)")
+        if mem.data.get("patch_embeddings") is None:
+            raise RuntimeError("teacher cache: the replay memory must hold pre-encoded ``patch_embeddings`` (it stores ``pixel_values``: "
+                               "encode them once with model.get_patch_embeddings before adding the samples)")
         layers = list(self.loss_weights.get_distillation_layers())
         n_hidden = max(layers) + 1
         lo, hi = mem.shard() if hasattr(mem, "shard") else (0, len(mem))
@@ -376,6 +390,11 @@ class FeatureDistillation(CLStrategy):
         T = data["input_ids"].shape[1]
         S, h = self.num_vision_tokens + T, pm.config.hidden_size
         n = hi - lo
+        if n <= 0:
+            raise RuntimeError(f"teacher cache: this rank's shard of the replay memory is empty ({len(mem)} samples over the ranks)")
+        if len(layers) * n * S >= 2 ** 31:
+            raise RuntimeError(f"teacher cache: {len(layers)} layers x {n} samples x {S} tokens = {len(layers) * n * S} rows exceed the 32-bit "
+                               "row ids of the gather kernel (shard the memory over more ranks or distil fewer layers)")
         t0 = time.time()
         states = torch.empty((len(layers), n, S, h), dtype=torch.float32, device=dev)
         with torch.no_grad():

@@ -96,7 +96,11 @@ class HBMReplayBuffer:
         if n == 0:
             raise RuntimeError("replay memory is empty")
         lo, hi = (n * self.rank) // self.world_size, (n * (self.rank + 1)) // self.world_size
-        m = max(1, hi - lo)
+        if hi <= lo:
+            # fewer samples than ranks: this rank's shard is empty (drawing index `lo` anyway would read another rank's sample, or past the
+            # end of the buffer on the last rank)
+            raise RuntimeError(f"replay memory: rank {self.rank} of {self.world_size} has an empty shard ({n} samples in the memory)")
+        m = hi - lo
         idx = torch.randperm(m, generator=self.gen)[: self.batch_size] + lo
         if self.device.type == "cuda":
             # pinned + non_blocking: a pageable .to(device) synchronises the stream, i.e. the host could not start

@@ -326,6 +326,13 @@ class VLPythiaForCausalLM(nn.Module):
     def side_stream(self):
         return self.side_streams()[0]
 
+    def _hook_zero(self) -> torch.Tensor:
+        """A zero scalar of this replica's device, filled once (value of the 0-dim hook outputs / gradients nobody reads)."""
+        z = getattr(self, "_hook_zero_t", None)
+        if z is None or z.device != self.flat_params.device:
+            z = self._hook_zero_t = torch.zeros(1, device=self.flat_params.device)
+        return z
+
     # ---- parameter views ---------------------------------------------------------------------------------------
     def sync_shadow(self):
         """Refresh the bf16 copy of the weights read by the MFMA GEMMs (the optimiser kernel keeps it current)."""
@@ -355,6 +362,22 @@ class VLPythiaForCausalLM(nn.Module):
 
     def zero_grad(self, set_to_none: bool = False):  # gradients are views of the flat buffer: always zero in place
         self.flat_grads.zero_()
+        self._dw_stale = False
+
+    def layer_matrix_range(self, i: int) -> Tuple[int, int]:
+        """Flat range of layer i's four weight matrices (query_key_value, dense, dense_h_to_4h, dense_4h_to_h: contiguous, behind the layer's
+        two LayerNorm weights in the decayed segment) -- the part of the gradient buffer that the grouped weight-gradient GEMMs write whole."""
+        pre = f"gpt_neox.layers.{i}."
+        lo = self._offsets[pre + "attention.query_key_value.weight"][0]
+        o, n, _ = self._offsets[pre + "mlp.dense_4h_to_h.weight"]
+        names = [pre + "attention.query_key_value.weight", pre + "attention.dense.weight", pre + "mlp.dense_h_to_4h.weight", pre + "mlp.dense_4h_to_h.weight"]
+        assert all(lo <= self._offsets[k][0] < o + n for k in names)
+        return lo, o + (n + 63) // 64 * 64
+
+    def _zero_layer_matrices(self, layers) -> None:
+        for i in layers:
+            lo, hi = self.layer_matrix_range(i)
+            self.flat_grads[lo:hi].zero_()
 
     def decay_split(self) -> int:
         """flat[:n] is weight-decayed, flat[n:] is not."""
@@ -673,14 +696,11 @@ class VLPythiaForCausalLM(nn.Module):
         # backward runs.  The persistent GEMMs assume all 256 of their blocks are resident at once -- with 8 CUs taken the late blocks run
         # a second wave and a launch takes 1.7x as long (tools/contention_bench.py: qkv 61.8 -> 105 us, grouped dW 440 -> 785), where the
         # 128 x 128 kernels' many small blocks lose 1.1 - 1.45x.  So this backward runs on those (Trainer sets the flag).
+        # (per call: every GEMM this thread issues inside the block carries MAFED_EPI_NO_PERSISTENT; no process-wide switch is touched, a
+        #  forced tuning variant or another thread's / model's launches are unaffected)
         if getattr(self, "contended_backward", False) and self.flat_params.is_cuda:
-            from mafed_amd import _lib as _l
-            lib = _l.load()
-            lib.mafed_gemm_set_variant(700)
-            try:
+            with ops.no_persistent_gemm():
                 return self._engine_backward_impl(sv, dloss, dhidden, taps)
-            finally:
-                lib.mafed_gemm_set_variant(701)
         return self._engine_backward_impl(sv, dloss, dhidden, taps)
 
     def _engine_backward_impl(self, sv, dloss: Optional[torch.Tensor], dhidden: Sequence[Optional[torch.Tensor]], taps=None):
@@ -737,6 +757,15 @@ class VLPythiaForCausalLM(nn.Module):
         # (beside collectives the weight gradients go back to one 128 x 128-kernel launch per product on the side streams, as in round 2:
         #  a grouped call would fall back to eight serial launches on the dX chain's stream)
         group_dw = cd == torch.bfloat16 and int(getattr(self, "dw_group_layers", 0)) > 0 and not getattr(self, "contended_backward", False)
+        # First micro-batch of an accumulation window (Trainer sets ``grad_overwrite``): the grouped weight-gradient GEMMs WRITE the layers'
+        # matrix gradients (beta = 0) instead of adding to a zeroed buffer -- the optimiser pass then does not zero-write those 1.2 GB
+        # (FlatAdamW: ``skip_matrix_zero``) and the GEMM epilogues do not read them back.  ``_dw_stale`` = the last optimiser pass left the
+        # matrices un-zeroed: a sweep that accumulates anyway (another caller, another kernel path) zeroes them first.
+        overwrite = group_dw and bool(getattr(self, "grad_overwrite", False)) and taps is None
+        if getattr(self, "_dw_stale", False) and not overwrite:
+            self._zero_layer_matrices(range(L))
+        self._dw_stale = False
+        dw_beta = 0.0 if overwrite else 1.0
         pending_dw: List[dict] = []
         pending_layers: List[int] = []
 
@@ -744,13 +773,16 @@ class VLPythiaForCausalLM(nn.Module):
             if not group_dw:
                 wgrad(dY, X, wname, bname)
                 return
-            pending_dw.append(dict(A=dY, B=X, out=g(wname), beta=1.0))
+            pending_dw.append(dict(A=dY, B=X, out=g(wname), beta=dw_beta))
             if bname is not None:
                 on_side(lambda: ops.colsum_(dY, g(bname)), dY)
 
         def flush_dw():
+            # at most PP_MAXP = 16 products per grouped launch (mafed_gemm_grouped launches larger lists one product at a time, serially on
+            # this stream -- worse than both forms): `dw_group_layers` >= 5 is cut into several launches
+            for c0 in range(0, len(pending_dw), 16):
+                ops.gemm_grouped(pending_dw[c0:c0 + 16], True, False)
             if pending_dw:
-                ops.gemm_grouped(pending_dw, True, False)
                 pending_dw.clear()
                 main_moved()
             for li in pending_layers:
@@ -824,6 +856,9 @@ class VLPythiaForCausalLM(nn.Module):
                 # but a distilled hidden_states[i] (this layer's input) still starts the gradient for the layers below
                 if inj is not None:
                     dx = ops.distill_bwd(sv["layers"][i]["x"].view(B, S, h), inj[0], am, P, inj[1], cosine=inj_cos).view(rows, h)
+                    main_moved()
+                if overwrite:
+                    self._zero_layer_matrices([i])   # (no weight-gradient GEMM will write this layer's matrices in this sweep)
                     main_moved()
                 continue
             if dy is None:
@@ -982,7 +1017,9 @@ class _ModelFn(torch.autograd.Function):
         # (after the distillation node has left its per-layer coefficients in sv["inject"]) even without a CE gradient; nobody reads
         # its value, so it is not filled
         pub = sv["logits"] if sv.get("sparse_head") is None else torch.empty(0, device=anchor.device)   # compact logits are internal
-        outs = [loss, pub.detach(), torch.empty((), device=anchor.device)]
+        # (one cached zero per device: an uninitialised scalar may hold NaN / Inf, which trips anomaly detection and would propagate if
+        #  autograd ever accumulated the hook's gradient with another path; re-using the tensor costs no fill kernel per step)
+        outs = [loss, pub.detach(), model._hook_zero().view(())]
         ctx.mark_non_differentiable(outs[1])
         if want_hidden:
             outs += [x.detach() for x in sv["hidden"]]  # aliases: no reference cycle through ctx

@@ -10,7 +10,10 @@ from typing import Optional, Tuple
 import torch
 
 from mafed_amd import _lib
-from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QUICK_GELU, EPI_RES1_BF16, F32, check  # noqa: F401
+import contextlib
+import threading
+
+from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NO_PERSISTENT, EPI_NONE, EPI_QUICK_GELU, EPI_RES1_BF16, F32, check  # noqa: F401
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -78,6 +81,22 @@ def workspace(device) -> Workspace:
     return ws
 
 
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def no_persistent_gemm(on: bool = True):
+    """Inside this block the CALLING THREAD's ``gemm`` / ``gemm_grouped`` calls carry MAFED_EPI_NO_PERSISTENT: each of those launches keeps
+    off the one-block-per-CU persistent kernels (e.g. a backward that runs beside collectives).  A per-call flag in the C-ABI, a
+    thread-local here: nothing process-wide is touched, other threads / models / forced tuning variants are unaffected."""
+    prev = getattr(_tls, "no_pp", 0)
+    _tls.no_pp = EPI_NO_PERSISTENT if on else prev
+    try:
+        yield
+    finally:
+        _tls.no_pp = prev
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Optional[torch.Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
          aux: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
@@ -95,6 +114,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
     assert out.shape == (M, N) and out.stride(1) == 1
     if res1 is not None and res1.dtype == torch.bfloat16:
         epilogue |= EPI_RES1_BF16
+    epilogue |= getattr(_tls, "no_pp", 0)
     if colsum is None:
         rc = _fn.gemm(_dt(A), int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
                       out.stride(0), _dt(out), _ptr(bias), epilogue, _ptr(aux), _ptr(res1), _ptr(res2), float(beta), _stream())
@@ -126,7 +146,7 @@ def gemm_grouped(problems, transA: bool, transB: bool) -> None:
         in_dt = _dt(A) if in_dt is None else in_dt
         out_dt = _dt(out) if out_dt is None else out_dt
         assert _dt(A) == in_dt and _dt(out) == out_dt, "a grouped launch shares its input and output types"
-        epi = q.get("epilogue", EPI_NONE)
+        epi = q.get("epilogue", EPI_NONE) | getattr(_tls, "no_pp", 0)
         res1 = q.get("res1")
         if res1 is not None and res1.dtype == torch.bfloat16:
             epi |= EPI_RES1_BF16
@@ -460,16 +480,24 @@ def gradnorm_finish(partials: torch.Tensor, max_norm: float, out2: torch.Tensor,
     return out2
 
 
-def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None, zero_grad: bool = False) -> None:
-    """``zero_grad``: the kernel also writes zeros over ``g`` (the next window's optimizer.zero_grad(), same pass)."""
+def adamw_step_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step, clip=None, grad_mul=1.0, p_bf16=None, zero_grad: bool = False,
+                zero_n: Optional[int] = None) -> None:
+    """``zero_grad``: the kernel also writes zeros over ``g`` (the next window's optimizer.zero_grad(), same pass); ``zero_n``: only over
+    its first ``zero_n`` elements (mafed_adamw_step_partial_zero: the rest is overwritten by the next window's weight-gradient GEMMs)."""
+    if zero_grad and zero_n is not None and zero_n < p.numel():
+        check(_lib.load().mafed_adamw_step_partial_zero(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
+                                                        int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), int(zero_n), _stream()), "mafed_adamw_step")
+        return
     fn = _lib.load().mafed_adamw_step_zero_grad if zero_grad else _lib.load().mafed_adamw_step
     check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, weight_decay,
              int(step), _ptr(clip), float(grad_mul), _ptr(p_bf16), _stream()), "mafed_adamw_step")
 
 
-def optim_advance_(state: torch.Tensor, base_lr: float, warmup: int, total: int, beta1: float, beta2: float, hyper: torch.Tensor) -> None:
-    check(_lib.load().mafed_optim_advance(_ptr(state), float(base_lr), int(warmup), int(total), float(beta1), float(beta2),
-                                          _ptr(hyper), _stream()), "mafed_optim_advance")
+def optim_advance_(state: torch.Tensor, base_lr: float, warmup: int, total: int, beta1: float, beta2: float, hyper: torch.Tensor,
+                   clip: Optional[torch.Tensor] = None) -> None:
+    """``clip`` = the {norm, scale} pair of this step's clip: a skipped step (scale < 0: non-finite norm) does not advance the counter."""
+    check(_lib.load().mafed_optim_advance_guarded(_ptr(state), float(base_lr), int(warmup), int(total), float(beta1), float(beta2),
+                                                  _ptr(hyper), _ptr(clip), _stream()), "mafed_optim_advance")
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

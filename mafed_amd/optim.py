@@ -78,14 +78,17 @@ class FlatAdamW:
         if getattr(self, "_advanced", False):
             self._advanced = False
             return
-        ops.optim_advance_(self.state_dev, self.base_lr, self._sched[0], self._sched[1], self.betas[0], self.betas[1], self.lr_dev)
+        # (with a clip pending the advance is guarded by it: a step whose gradient norm was not finite is skipped on the device --
+        #  no parameter / state update in the AdamW kernel, no step-counter advance here; the host sees the non-finite norm in its log)
+        ops.optim_advance_(self.state_dev, self.base_lr, self._sched[0], self._sched[1], self.betas[0], self.betas[1], self.lr_dev,
+                           clip=self.clip_out if getattr(self, "_clip_pending", False) else None)
 
     def host_advance(self) -> None:
         """Host mirror of the step counter (logging, state_dict); no device work."""
         self.step_count += 1
 
     def zero_grad(self, set_to_none: bool = False) -> None:
-        self.model.flat_grads.zero_()
+        self.model.zero_grad()
 
     # ---- global-norm clip ------------------------------------------------------------------------------------------------
     def _norm_plan(self):
@@ -173,11 +176,18 @@ class FlatAdamW:
         self.advance()
         self.apply(grad_mul)
 
-    def apply(self, grad_mul: float = 1.0, zero_grads: bool = False) -> None:
+    def apply(self, grad_mul: float = 1.0, zero_grads: bool = False, skip_matrix_zero: bool = False) -> None:
         """Device half of a step: the AdamW kernels, reading this step's scalars from device memory.  ``zero_grads``: the same
-        pass also zeroes the gradient buffer (optimizer.zero_grad() of the next window)."""
+        pass also zeroes the gradient buffer (optimizer.zero_grad() of the next window).  ``skip_matrix_zero`` (with ``zero_grads``): the
+        layers' weight-matrix gradients are left as they are -- the next window's first backward overwrites them (model.grad_overwrite)."""
         m = self.model
         clip = self.clip_out if getattr(self, "_clip_pending", False) else None
+        if zero_grads and skip_matrix_zero:
+            self._apply_chunks(clip, grad_mul)
+            self._clip_pending = False
+            if m.flat_shadow is not None:
+                m._shadow_dirty = False
+            return
         for grp in self.param_groups:
             lo, hi = grp["range"]
             if hi <= lo:
@@ -188,6 +198,24 @@ class FlatAdamW:
         self._clip_pending = False
         if m.flat_shadow is not None:
             m._shadow_dirty = False
+
+    def _apply_chunks(self, clip, grad_mul: float, skip_matrix_zero: bool = True, events: Optional[dict] = None, stream=None):
+        """One AdamW launch per chunk of ``_chunks()`` on the current stream, the gradient zeroed in the same pass; a layer chunk zeroes only
+        its LayerNorm-weight part when ``skip_matrix_zero`` (mafed_adamw_step_partial_zero)."""
+        m = self.model
+        for key, lo, hi, wd in self._chunks():
+            shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
+            zn = None
+            if skip_matrix_zero and isinstance(key, tuple) and key[0] == "layer":
+                mlo, mhi = m.layer_matrix_range(key[1])
+                assert lo <= mlo and mhi == hi, "layer chunk = [LayerNorm weights | weight matrices]"
+                zn = mlo - lo
+            ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
+                            self.betas[0], self.betas[1], self.eps, wd, 0, clip, grad_mul, shadow, zero_grad=True, zero_n=zn)
+            if events is not None:
+                events[key] = stream.record_event()
+        if skip_matrix_zero:
+            m._dw_stale = True   # (cleared by the next backward sweep: it overwrites the matrices, or zeroes them first)
 
     def _chunks(self):
         """(key, lo, hi, weight_decay) in the order the NEXT forward touches the parameters: everything the first kernels
@@ -203,7 +231,7 @@ class FlatAdamW:
         assert sum(hi - lo for _, lo, hi, _ in out) == m.flat_params.numel(), "optimizer chunks must tile the flat buffer"
         return [c for c in out if c[2] > c[1]]
 
-    def apply_pipelined(self, stream, grad_mul: float = 1.0, zero_grads: bool = True):
+    def apply_pipelined(self, stream, grad_mul: float = 1.0, zero_grads: bool = True, skip_matrix_zero: bool = False):
         """AdamW (and the gradient zeroing) chunk by chunk on ``stream``, one event per chunk group: the next forward waits
         for "pre", then for ("layer", i) right before layer i, then for "head" -- so the HBM-bound update of the upper layers
         runs under the MFMA-bound forward of the lower ones instead of in front of it.  The caller's stream must not touch
@@ -214,11 +242,14 @@ class FlatAdamW:
         stream.wait_event(main.record_event())  # gradients final, clip scale and {lr, bias corrections} on the device
         events = {}
         with torch.cuda.stream(stream):
-            for key, lo, hi, wd in self._chunks():
-                shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
-                ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
-                                self.betas[0], self.betas[1], self.eps, wd, 0, clip, grad_mul, shadow, zero_grad=zero_grads)
-                events[key] = stream.record_event()
+            if zero_grads:
+                self._apply_chunks(clip, grad_mul, skip_matrix_zero=skip_matrix_zero, events=events, stream=stream)
+            else:
+                for key, lo, hi, wd in self._chunks():
+                    shadow = m.flat_shadow[lo:hi] if m.flat_shadow is not None else None
+                    ops.adamw_step_(m.flat_params[lo:hi], m.flat_grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr_dev,
+                                    self.betas[0], self.betas[1], self.eps, wd, 0, clip, grad_mul, shadow, zero_grad=False)
+                    events[key] = stream.record_event()
         self._clip_pending = False
         if m.flat_shadow is not None:
             m._shadow_dirty = False

@@ -176,3 +176,46 @@ def test_global_counts_are_the_identity_without_a_process_group():
     from mafed_amd.methods.distillation import global_token_counts
     s = torch.rand(3, 4)
     assert global_token_counts(s) is s
+
+
+# ---- validation metrics under data parallelism (mafed/utils/eval_utils.py:89-90,135-137) -------------------------------------------
+def _metric_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mafed_amd.dist import generative_accuracy, reduce_validation_metrics
+        # rank r saw 100 + r examples, loss sum 1.5 * (r + 1), score sum 10 * (r + 1); one rank holds more than 2^24 examples
+        n_ex = 100 + rank + (2 ** 24 + 1 if rank == 0 else 0)
+        out = reduce_validation_metrics(n_ex, 1.5 * (rank + 1), 10.0 * (rank + 1))
+        acc = generative_accuracy(0.3 * (rank + 1), 10 * (rank + 1))
+        q.put((rank, out, acc))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_validation_metric_sums_over_ranks(world):
+    """The reference sums (n_ex, val_loss, tot_score) over the ranks before dividing (eval_utils.py:135-137); the torchmetrics states
+    of VQAGenerativeAccuracy reduce by sum as well (:89-90).  Every rank gets the global sums, exactly."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metric_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    tri = world * (world + 1) / 2
+    want = (sum(100 + r for r in range(world)) + 2 ** 24 + 1, 1.5 * tri, 10.0 * tri)
+    for rank, out, acc in res:
+        assert out[0] == want[0], (rank, out)          # beyond 2^24: would round in fp32
+        assert abs(out[1] - want[1]) < 1e-9 and abs(out[2] - want[2]) < 1e-9
+        assert abs(acc - (0.3 * tri) / (10 * tri)) < 1e-12
+
+
+def test_validation_metric_reduction_is_the_identity_in_one_process():
+    from mafed_amd.dist import generative_accuracy, reduce_validation_metrics
+    assert reduce_validation_metrics(7, 2.5, 3.0) == (7.0, 2.5, 3.0)
+    assert generative_accuracy(3.0, 10) == 0.3

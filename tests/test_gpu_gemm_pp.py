@@ -256,3 +256,132 @@ def test_grouped_call_falls_back_to_one_launch_per_problem():
     for q in many:
         r = _ref(q["A"].float().cpu(), q["B"].float().cpu(), True, False)
         assert float((q["out"].double().cpu() - r).abs().max()) == 0.0
+
+
+# ---- ticketed tile order (round 4) --------------------------------------------------------------------------------------------------
+class tile_order:
+    """mafed_gemm_set_variant(720 / 721) around a block; restores the mode that was set."""
+
+    def __init__(self, ticketed):
+        self.v = 721 if ticketed else 720
+
+    def __enter__(self):
+        self.lib = _lib()
+        self.prev = self.lib.mafed_gemm_get_variant(72)
+        self.lib.mafed_gemm_set_variant(self.v)
+
+    def __exit__(self, *a):
+        self.lib.mafed_gemm_set_variant(self.prev)
+
+
+def _occupy(stream, blocks, cycles=int(8e6)):
+    """`blocks` CUs held by a sleeping 512-thread workgroup each for ~4 ms (mafed_tune_occupy), launched on `stream`."""
+    from mafed_amd import _lib as L
+    L.check(_lib().mafed_tune_occupy(blocks, 96 * 1024, cycles, stream.cuda_stream), "occupy")
+
+
+TICKET_COMBOS = [(0, False, True, BF), (0, False, True, F32), (0, False, False, BF), (1, True, False, F32)]
+
+
+@pytest.mark.parametrize("cfg,tA,tB,od", TICKET_COMBOS)
+@pytest.mark.parametrize("occupied", [0, 24, 250])
+def test_pp_ticketed_order_is_exact_with_cus_taken(cfg, tA, tB, od, occupied):
+    """Every tile exactly once, whatever part of the chip another stream holds: integer operands, several rounds of short tiles (K = 256:
+    the ticket draws follow each other as fast as they ever will), launches back to back on one stream (the two ticket slots alternate)
+    while `occupied` CUs are held by a sleeping kernel -- 250 leaves six blocks to draw every tile.  The fp32 cases accumulate into C
+    (beta = 1): a tile computed twice, or never, shows."""
+    ops = _ops()
+    lib = _lib()
+    g = torch.Generator().manual_seed(21 + cfg)
+    tiles_m, tiles_n, K = 40, 12, 256          # 480 tiles: one static round + 224 drawn
+    M, N = TM[cfg] * tiles_m, 256 * tiles_n
+    A = _int_mat((K, M) if tA else (M, K), g)
+    B = _int_mat((N, K) if tB else (K, N), g)
+    ref = _ref(A, B, tA, tB)
+    Ad, Bd = A.to(DEV, BF), B.to(DEV, BF)
+    side = torch.cuda.Stream()
+    with tile_order(True), forced(cfg, expect=3):
+        n0 = lib.mafed_gemm_get_variant(73)
+        torch.cuda.synchronize()
+        if occupied:
+            _occupy(side, occupied)
+            torch.cuda._sleep(400000)      # the occupier's blocks take their CUs first
+        outs = []
+        for rep in range(3):
+            if od == F32:
+                C = torch.full((M, N), float(rep + 1), dtype=F32, device=DEV)
+                ops.gemm(Ad, Bd, tA, tB, out=C, beta=1.0)
+            else:
+                C = ops.gemm(Ad, Bd, tA, tB, out_dtype=od)
+            outs.append(C)
+        torch.cuda.synchronize()
+        assert lib.mafed_gemm_get_variant(73) - n0 == 3, "the launches did not run in ticketed order"
+    for rep, C in enumerate(outs):
+        want = ref + (rep + 1) if od == F32 else ref.to(BF).double()
+        err = float((C.double().cpu() - want).abs().max())
+        assert err == 0.0, f"launch {rep}: max err {err} (cfg {cfg}, {occupied} CUs taken)"
+
+
+def test_pp_ticketed_order_two_streams_at_once():
+    """Ticketed launches of two streams at the same time use different slots: both exact."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 144 * 40, 256 * 12, 256
+    A, B = _int_mat((M, K), g), _int_mat((N, K), g)
+    ref = _ref(A, B, False, True).to(BF).double()
+    Ad, Bd = A.to(DEV, BF), B.to(DEV, BF)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    with tile_order(True):
+        for _ in range(4):
+            for s in (s1, s2):
+                with torch.cuda.stream(s):
+                    outs.append(ops.gemm(Ad, Bd, False, True, out_dtype=BF))
+        torch.cuda.synchronize()
+    for C in outs:
+        assert float((C.double().cpu() - ref).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["gelu", "gelu_bwd_colsum", "residual"])
+def test_pp_ticketed_order_equals_static_order_with_epilogues(mode):
+    """The step's fused epilogues over several rounds: ticketed order == static order, bit for bit (column sums: same tiles, another
+    order of the float atomics)."""
+    from mafed_amd._lib import EPI_GELU, EPI_GELU_BWD
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    M, N, K = 144 * 24, 256 * 16, 512     # 384 tiles
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV, BF)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = {}
+    for ticketed in (False, True):
+        with tile_order(ticketed):
+            if mode == "gelu":
+                W = (torch.randn(N, K, generator=g.manual_seed(42)) * 0.5).to(DEV, BF)
+                aux = torch.empty((M, N), dtype=BF, device=DEV)
+                y = ops.gemm(A, W, False, True, bias=bias, epilogue=EPI_GELU, aux=aux)
+                res[ticketed] = (y, aux)
+            elif mode == "gelu_bwd_colsum":
+                W = (torch.randn(K, N, generator=g.manual_seed(43)) * 0.5).to(DEV, BF)
+                u = torch.randn(M, N, generator=g.manual_seed(44)).to(DEV, BF)
+                cs = torch.zeros(N, dtype=F32, device=DEV)
+                y = ops.gemm(A, W, False, False, epilogue=EPI_GELU_BWD, aux=u, colsum=cs)
+                res[ticketed] = (y, cs)
+            else:
+                W = (torch.randn(N, K, generator=g.manual_seed(45)) * 0.5).to(DEV, BF)
+                r1 = torch.randn(M, N, generator=g.manual_seed(46)).to(DEV, BF)
+                r2 = torch.randn(M, N, generator=g.manual_seed(47)).to(DEV)
+                lib = _lib()
+                lib.mafed_gemm_set_variant(710)   # (the fp32 + two-residual epilogue takes the persistent kernel only when forced)
+                try:
+                    y = ops.gemm(A, W, False, True, bias=bias, out_dtype=F32, res1=r1, res2=r2)
+                finally:
+                    lib.mafed_gemm_set_variant(701)
+                res[ticketed] = (y,)
+    torch.cuda.synchronize()
+    assert torch.equal(res[False][0], res[True][0])
+    if mode == "gelu":
+        assert torch.equal(res[False][1], res[True][1])
+    if mode == "gelu_bwd_colsum":
+        a, b = res[False][1], res[True][1]
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())

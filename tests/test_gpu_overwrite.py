@@ -1,0 +1,152 @@
+"""Overwrite-mode weight gradients: on the first micro-batch of an accumulation window the grouped weight-gradient
+GEMMs WRITE the layers' matrix gradients (beta = 0) and the AdamW pass does not zero them (mafed_adamw_step_partial_zero); later
+micro-batches accumulate.  The steps must equal the classic "zero, then accumulate" steps -- in both optimiser pipeline modes, with
+accumulate_grad_batches 1 and 4, when a layer's backward is skipped, and when a foreign backward accumulates into un-zeroed matrices
+(reference semantics: optimizer.zero_grad() + AdamW.step, mafed/optim/adamw.py:50-113, mafed/train.py:288)."""
+import types
+
+import pytest
+import torch
+
+from oracle import vlpythia_ref as R
+from tests.helpers import tiny_cfg
+from tests.test_gpu_replay import _conf, _dataset, _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mafed(cfg, teacher, mem_batches, P):
+    from mafed_amd import FeatureDistillation
+    opts = types.SimpleNamespace(tasks=["a", "b"], batch_size=4, seed=1, pin_mem=False, accumulate_grad_batches=1)
+    fd = FeatureDistillation(memory_size=16, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                             distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                             gamma=0.5, distillation_layer=None)
+    fd._update_model(teacher)
+    fd.task_id = 1
+    fd.num_vision_tokens = P
+    return fd
+
+
+def _steps(name, overwrite, pipeline, accumulate, n_micro, replay_interval=1):
+    from mafed_amd import Trainer
+    cfg = tiny_cfg(name)
+    sd = R.init_weights(cfg, seed=3, bias_std=0.02, ln_jitter=0.05)
+    tsd = R.perturb(sd, seed=4, std=5e-3)
+    student, teacher = _model(cfg, sd, torch.bfloat16), _model(cfg, tsd, torch.bfloat16)
+    student.dw_group_layers = 2
+    data = _dataset(cfg, 4 * n_micro, 6, seed=50)
+    batches = [{k: v[4 * i: 4 * i + 4].to(DEV) for k, v in data.items()} for i in range(n_micro)]
+    fd = _mafed(cfg, teacher, batches, cfg.num_vision_tokens)
+    conf = _conf(lr=1e-3, accumulate=accumulate)
+    conf.replay_interval = replay_interval
+    tr = Trainer(student, fd, conf, task_id=1, pipeline_optimizer=pipeline, overwrite_weight_grads=overwrite)
+    assert tr._overwrite_ok() == overwrite
+    losses, gns = [], []
+    for i in range(n_micro):
+        fd.mem_dataloader = [dict(batches[i])]
+        rec = tr.step(dict(batches[(i + 1) % n_micro]), i)
+        losses.append(float(rec["loss"]))
+        if rec["stepped"]:
+            gns.append(float(rec["grad_norm"]))
+    tr.join()
+    torch.cuda.synchronize()
+    return losses, gns, student.flat_params.clone(), student
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+@pytest.mark.parametrize("accumulate,replay_interval", [(1, 1), (4, 4), (2, 1)])
+def test_overwrite_equals_zero_then_accumulate(pipeline, accumulate, replay_interval):
+    a = _steps("t64", True, pipeline, accumulate, 8, replay_interval)
+    b = _steps("t64", False, pipeline, accumulate, 8, replay_interval)
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), f"micro-batch {i}: loss {x} vs {y}"
+    assert len(a[1]) == 8 // accumulate
+    for i, (x, y) in enumerate(zip(a[1], b[1])):
+        assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), f"step {i}: grad norm {x} vs {y}"
+    d = float((a[2] - b[2]).abs().max())
+    assert d <= 2e-5, f"parameters differ by {d} after {8 // accumulate} optimiser steps"
+    assert a[3]._dw_stale and not b[3]._dw_stale   # the overwrite run really left the matrices to the next sweep
+
+
+def test_a_foreign_backward_after_an_overwrite_step_starts_from_zero():
+    """After an overwrite-mode optimiser step the matrices' gradient buffer holds the last gradient; a backward that accumulates
+    (here: a plain loss.backward() outside the Trainer) must not add to it."""
+    _, _, _, student = _steps("t64", True, True, 1, 2)
+    cfg = tiny_cfg("t64")
+    batch = {k: v.to(DEV) for k, v in R.make_batch(cfg, 4, 6, seed=77, pad=True, n_answer=3).items()}
+    assert student._dw_stale
+    out = student(**batch, return_dict=True)
+    out.loss.backward()
+    g1 = student.flat_grads.clone()
+    student.zero_grad()
+    out = student(**batch, return_dict=True)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    lo, hi = student.layer_matrix_range(0)
+    ref = student.flat_grads[lo:hi]
+    assert float(ref.abs().max()) > 0
+    assert float((g1[lo:hi] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def test_partial_zero_adamw_kernel():
+    """mafed_adamw_step_partial_zero: same update as mafed_adamw_step, g zeroed on [0, zero_n) only; a skipped step (clip scale < 0)
+    still zeroes that part and nothing else."""
+    from mafed_amd import ops
+    n, zn = 4096 + 8, 1024
+    g = torch.Generator(device=DEV).manual_seed(0)
+    p0 = torch.randn(n, device=DEV, generator=g)
+    gr = torch.randn(n, device=DEV, generator=g)
+    m0, v0 = torch.rand(n, device=DEV, generator=g) * 0.1, torch.rand(n, device=DEV, generator=g) * 0.01
+    lr_dev = torch.tensor([1e-2, 0.1, 0.3], device=DEV)
+    clip = torch.tensor([3.0, 0.5], device=DEV)
+
+    def run(zero_n, clip_t):
+        p, gg, m, v = p0.clone(), gr.clone(), m0.clone(), v0.clone()
+        sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        ops.adamw_step_(p, gg, m, v, lr_dev, 0.9, 0.98, 1e-6, 0.01, 0, clip_t, 1.0, sh, zero_grad=zero_n is not None, zero_n=zero_n)
+        return p, gg, m, v, sh
+
+    ref = run(None, clip)
+    out = run(zn, clip)
+    for a, b in zip(ref[:1] + ref[2:], out[:1] + out[2:]):
+        assert torch.equal(a, b)
+    assert float(out[1][:zn].abs().max()) == 0.0 and torch.equal(out[1][zn:], gr[zn:])
+    skip = run(zn, torch.tensor([float("nan"), -1.0], device=DEV))
+    assert torch.equal(skip[0], p0) and torch.equal(skip[2], m0) and torch.equal(skip[3], v0)
+    assert float(skip[1][:zn].abs().max()) == 0.0 and torch.equal(skip[1][zn:], gr[zn:])
+
+
+def test_non_finite_gradient_norm_skips_the_update():
+    """a NaN loss (e.g. the row-sparse head's overflow poison) must not reach the parameters: the norm kernels publish clip
+    scale -1, AdamW leaves p / m / v / shadow alone, the step counter does not advance, the gradient buffer is zeroed for the next
+    window -- and the host sees the non-finite norm in the step's record."""
+    from mafed_amd import Trainer
+    from mafed_amd.methods import Naive
+    cfg = tiny_cfg("t64")
+    sd = R.init_weights(cfg, seed=3, bias_std=0.02, ln_jitter=0.05)
+    for pipeline in (False, True):
+        student = _model(cfg, sd, torch.bfloat16)
+        tr = Trainer(student, Naive(), _conf(lr=1e-3), task_id=0, pipeline_optimizer=pipeline)
+        batch = {k: v.to(DEV) for k, v in R.make_batch(cfg, 4, 6, seed=5, pad=True, n_answer=3).items()}
+        tr.step(dict(batch), 0)
+        tr.join()
+        torch.cuda.synchronize()
+        p1, m1, t1 = student.flat_params.clone(), tr.optimizer.exp_avg.clone(), int(tr.optimizer.state_dev)
+        assert t1 == 1
+        hook = student.register_forward_hook(lambda mod, a, out: setattr(out, "loss", out.loss * float("nan")) or out)
+        rec = tr.step(dict(batch), 1)
+        hook.remove()
+        tr.join()
+        torch.cuda.synchronize()
+        assert not torch.isfinite(rec["grad_norm"]).item()
+        assert torch.equal(student.flat_params, p1) and torch.equal(tr.optimizer.exp_avg, m1)
+        assert int(tr.optimizer.state_dev) == 1, "the device step counter advanced on a skipped step"
+        lo, hi = student.layer_matrix_range(0)
+        bias_seg = student.flat_grads[student.decay_split():]
+        assert float(bias_seg.abs().max()) == 0.0      # zeroed for the next window (the matrices are overwritten by it instead)
+        rec = tr.step(dict(batch), 2)                  # and training goes on
+        tr.join()
+        torch.cuda.synchronize()
+        assert torch.isfinite(rec["grad_norm"]).item() and int(tr.optimizer.state_dev) == 2
+        assert torch.isfinite(student.flat_params).all()

@@ -287,3 +287,46 @@ def test_runtime_env_is_opt_in_and_respects_the_environment(monkeypatch):
         warnings.simplefilter("always")
         env = mafed_amd.apply_recommended_runtime_env()
     assert env["HIP_FORCE_DEV_KERNARG"] is None and any("no effect" in str(x.message) for x in w)
+
+
+def test_no_persistent_gemm_flag_is_per_thread_and_restores():
+    """the data-parallel backward's kernel choice is a per-call flag (MAFED_EPI_NO_PERSISTENT), thread-local on the host --
+    not a process-wide switch that a forced tuning variant or another thread's launches would see."""
+    import threading
+    from mafed_amd import ops
+    from mafed_amd._lib import EPI_NO_PERSISTENT
+    seen = {}
+
+    def other():
+        seen["other"] = getattr(ops._tls, "no_pp", 0)
+
+    assert getattr(ops._tls, "no_pp", 0) == 0
+    with ops.no_persistent_gemm():
+        assert ops._tls.no_pp == EPI_NO_PERSISTENT
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        with ops.no_persistent_gemm(False):      # nested "leave it as it is"
+            assert ops._tls.no_pp == EPI_NO_PERSISTENT
+        try:
+            with ops.no_persistent_gemm():
+                raise ValueError
+        except ValueError:
+            pass
+        assert ops._tls.no_pp == EPI_NO_PERSISTENT
+    assert ops._tls.no_pp == 0 and seen["other"] == 0
+
+
+def test_replay_buffer_refuses_an_empty_rank_shard():
+    """with fewer samples than ranks a shard is empty; drawing index `lo` anyway read another rank's sample (or past the end)."""
+    import torch
+    from mafed_amd.methods import HBMReplayBuffer
+    data = {"input_ids": torch.arange(6).view(3, 2), "attention_mask": torch.ones(3, 2, dtype=torch.int64),
+            "labels": torch.arange(6).view(3, 2), "patch_embeddings": torch.zeros(3, 4, 8)}
+    ok = HBMReplayBuffer(2, torch.device("cpu"), seed=0, rank=1, world_size=3)
+    ok.add(data)
+    assert ok._draw()["input_ids"].shape[0] == 1
+    empty = HBMReplayBuffer(2, torch.device("cpu"), seed=0, rank=0, world_size=5)    # (3 * 0) // 5 == (3 * 1) // 5 == 0: rank 0's shard is empty
+    empty.add(data)
+    with pytest.raises(RuntimeError, match="empty shard"):
+        empty._draw()

@@ -47,3 +47,19 @@ def test_z_kernel_index_maps_and_bank_conflicts(c):
     for key, ways in worst.items():
         allowed = 2 if (key == "B:tr" and c.pair) else 1
         assert ways <= allowed, (key, ways)
+
+
+@pytest.mark.timeout(600)
+def test_ticket_register_is_left_alone_in_the_built_isa():
+    """The ticketed tile order of gemm_pp.hip lands a returning atomic in v255 up to a microsecond after the asm statement: the ISA of
+    every instantiation must not touch v252 - v255 anywhere else (tools/pp_ticket_audit.py), the synchronous form of the weight-gradient
+    kernel must carry its own wait, and no kernel may have scratch."""
+    import shutil
+    import pp_ticket_audit as T
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    rows = T.audit(T.compile_isa())
+    assert len(rows) >= 4
+    for r in rows:
+        assert not r["problems"], (r["kernel"], r["problems"])
+        assert r["atomics"] >= 2 and (r["sync"] or r["parks"] >= 2)
