@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--rccl-channels", type=int, default=None, help="N > 1: pin RCCL's channel count (NCCL_MIN/MAX_NCHANNELS)")
     ap.add_argument("--memory-size", type=int, default=4000, help="samples resident in the HBM replay memory (the reference's --memory_size)")
     ap.add_argument("--exact-normaliser", action="store_true", help="N > 1: distillation means over the GLOBAL token counts (one small all-reduce)")
+    ap.add_argument("--no-ddp-forecast", action="store_true", help="N = 1: skip the emulated-collectives leg (`ddp_forecast` key)")
+    ap.add_argument("--emulate-channels", type=int, default=16, help="N = 1 forecast: workgroups of the stand-in collective kernel (RCCL channels)")
+    ap.add_argument("--no-ticketed-order", action="store_true", help="persistent GEMM kernels in the static tile order of round 3 (A/B)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -230,6 +233,9 @@ def main():
     if args.gemm_variant is not None:
         from mafed_amd import _lib
         _lib.load().mafed_gemm_set_variant(args.gemm_variant)
+    if args.no_ticketed_order:
+        from mafed_amd import _lib
+        _lib.load().mafed_gemm_set_variant(720)
     rank, local, world = init_from_env()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
@@ -383,6 +389,46 @@ def main():
         dump_profile(args.dump_profile, "kernel_profile_no_overlap.csv", kp1, rank)
         student.overlap_param_grads, fd.overlap_teacher, tr.pipeline_optimizer = ov
         barrier()
+
+    # Forecast of the N-GPU step on ONE GPU (no multi-GPU node has ever been available to this build -- this is NOT a scaling measurement):
+    # the same step with dist.EmulatedReducer in place of the gradient exchange: per bucket, `--emulate-channels` workgroups stream memory
+    # on the reducer's side stream for the time that bucket's all-reduce would take, beside the backward.  Two exchange durations (SURVEY
+    # section 5: 2.7 ms with all seven xGMI links busy, 18.6 ms for one ring) x the two ways the backward beside it can run: the persistent
+    # kernels in ticketed order, or every GEMM of that backward on the 128 x 128 kernels (MAFED_EPI_NO_PERSISTENT, round 3's choice).
+    ddp_forecast = None
+    if world == 1 and not args.no_ddp_forecast:
+        from mafed_amd.dist import EmulatedReducer
+        tr.join()
+        rows = []
+        n_f = max(5, args.steps // 2)
+        for ar_ms in (2.7, 18.6):
+            for mode in ("persistent_ticketed", "128x128"):
+                student.zero_grad()
+                red = EmulatedReducer(student, ar_ms, channels=args.emulate_channels, bucket_mb=args.bucket_mb)
+                trf = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, pipeline_optimizer=not args.no_pipeline_optimizer,
+                              incremental_norm=not args.no_incremental_norm, reducer=red)
+                trf.contention_aware = mode == "128x128"
+                for i in range(3):
+                    trf.step(task_batch, 20_000 + i)
+                torch.cuda.synchronize()
+                red.time_wait = True
+                tf0 = time.perf_counter()
+                for i in range(n_f):
+                    rec_f = trf.step(task_batch, 20_003 + i)
+                torch.cuda.synchronize()
+                dtf = time.perf_counter() - tf0
+                waits = red.exposed_wait_ms()
+                trf.join()
+                student.grad_ready_hook = None
+                student.contended_backward = False
+                rows.append({"allreduce_ms": ar_ms, "kernel_mode": mode, "ms_per_step": round(dtf / n_f * 1e3, 3),
+                             "reducer_wait_ms": round(sum(waits) / max(1, len(waits)), 3), "final_loss": round(float(rec_f["loss"]), 5)})
+                log(f"ddp forecast: all-reduce {ar_ms} ms, {mode}: {dtf / n_f * 1e3:.2f} ms per step, reducer wait {rows[-1]['reducer_wait_ms']:.2f} ms")
+        ddp_forecast = {"what": "ONE GPU, emulated gradient exchange (dist.EmulatedReducer: per bucket, `channels` workgroups streaming memory for the "
+                                "bucket's share of `allreduce_ms`, on the reducer's stream beside the backward); a forecast of the per-GPU step "
+                                "under data parallelism, not a scaling measurement", "channels": args.emulate_channels, "emulated_world": 8,
+                        "buckets": len(red.buckets), "MB_per_step": round(red.bytes_per_step / 1e6, 1), "steps": n_f, "rows": rows}
+        student.zero_grad()
 
     # MI355X-only design point, reported BESIDE the headline (never instead of it: the step above runs the teacher forward, as SURVEY 8d
     # defines it): the frozen teacher's distilled hidden states for this rank's whole replay memory stay resident in HBM
@@ -604,6 +650,7 @@ def main():
                           "global_batch": B * world, "per_gpu_batch": B, "seq_len": P + T, "parallelism": f"dp{world}",
                           "random_init_weights": True},
                "ranks_joined": ranks_joined, "dist_backend": backend, "runtime_env": runtime_env(),
+               "gemm_tile_order": "static" if args.no_ticketed_order else "ticketed",
                "replay_memory": {"samples": len(mem), "HBM_MB": round(sum(v.numel() * v.element_size() for v in mem.data.values() if v is not None) / 1e6, 1)},
                "step_tflops_algorithmic": round(flops_step / 1e12, 3),
                "mfma_frac_whole_step": round(flops_exec * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5),
@@ -634,6 +681,8 @@ def main():
             out["image_input"] = image_leg
         if teacher_cache:
             out["teacher_cache"] = teacher_cache
+        if ddp_forecast:
+            out["ddp_forecast"] = ddp_forecast
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model, P, T)

@@ -85,6 +85,10 @@ typedef struct mafed_gemm_problem {
   void* C; int64_t ldc;
   const float* bias; int epilogue; void* aux;
   const float* res1; const float* res2; float beta; float* colsum;
+  float* sumsq; /* NULL, or 16 floats: sumsq[k] += the squares of part of the STORED C (fp32 C only; which tile adds to which of the 16 slots
+                   is unspecified, their total is sum C^2).  The weight-gradient products of a window's last micro-batch leave the squared
+                   norm of the final gradient here, so that the clip's norm pass (mafed_gradnorm_partial, 1.2 GB at 410M) skips the
+                   matrices (mafed/train.py:288 clip_grad_norm_). */
 } mafed_gemm_problem;
 int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, mafed_dtype c_dtype,
                        const mafed_gemm_problem* problems, int n, void* stream);
@@ -287,6 +291,10 @@ int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps
 int mafed_optim_advance_guarded(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1, double beta2,
                                 float* hyper3_dev, const float* clip_dev, void* stream);
 
+/* sumsq16[k] += the squares of part of x (k = 0..15, their total += sum x^2): the unfused form of mafed_gemm_problem.sumsq, and the way
+ * to put any fp32 range into the same 16 slots.  x 16-byte aligned. */
+int mafed_sumsq_accumulate(const float* x, int64_t n, float* sumsq16, void* stream);
+
 /* mafed_gradnorm_finish followed by mafed_optim_advance as ONE launch (both are single-thread tails on the optimiser step's critical
  * path); norm_log (or NULL) additionally receives the norm -- a slot the caller owns, e.g. for the step's log record, so that no
  * device copy of out2[0] is needed before the next step overwrites it.  Same arithmetic, bit for bit, as the two calls. */
@@ -367,6 +375,9 @@ int mafed_tune_occupy(int blocks, int lds_bytes, long long cycles, void* stream)
  * (2 / 4 / 8) loads in flight per thread; mode 0 reads, 1 copies to dst, 2 = four read + four written streams of n_bytes / 4 (AdamW-shaped).
  * Measures what a FEW CUs stream from HBM while the rest of the chip does something else (tools/stream_cu_bench.py). */
 int mafed_tune_stream(const void* src, void* dst, long long n_bytes, int blocks, int threads, int unroll, int mode, void* stream);
+/* The AdamW-shaped sweep of mafed_tune_stream, repeated over the buffer for `microseconds` of wall time (100 MHz device clock): a stand-in
+ * for the kernels of ONE bucket's all-reduce -- `blocks` = RCCL channels -- on a single GPU (bench.py --emulate-collectives). */
+int mafed_tune_stream_for(const void* src, void* dst, long long n_bytes, int blocks, int threads, double microseconds, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mafed_gradnorm_blocks": (_i, [_l]),
     "mafed_gradnorm_partial": (_i, [_p, _l, _p, _p]),
     "mafed_gradnorm_finish": (_i, [_p, _i, _f, _p, _p]),
+    "mafed_sumsq_accumulate": (_i, [_p, _l, _p, _p]),
     "mafed_adamw_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
     "mafed_adamw_step_zero_grad": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _p]),
     "mafed_adamw_step_partial_zero": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _i, _p, _f, _p, _l, _p]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "mafed_optim_advance_guarded": (_i, [_p, _d, _l, _l, _d, _d, _p, _p, _p]),
     "mafed_tune_occupy": (_i, [_i, _i, C.c_longlong, _p]),
     "mafed_tune_stream": (_i, [_p, _p, C.c_longlong, _i, _i, _i, _i, _p]),
+    "mafed_tune_stream_for": (_i, [_p, _p, C.c_longlong, _i, _i, _d, _p]),
     "mafed_gradnorm_finish_advance": (_i, [_p, _i, _f, _p, _p, _p, _d, _l, _l, _d, _d, _p, _p]),
     "mafed_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "mafed_pad_text_rows": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
@@ -87,7 +89,7 @@ SIGNATURES = {
 class GemmProblem(C.Structure):
     """``mafed_gemm_problem`` of include/mafed_hip.h (one entry of a grouped launch)."""
     _fields_ = [("M", _l), ("N", _l), ("K", _l), ("A", _p), ("lda", _l), ("B", _p), ("ldb", _l), ("C", _p), ("ldc", _l),
-                ("bias", _p), ("epilogue", _i), ("aux", _p), ("res1", _p), ("res2", _p), ("beta", _f), ("colsum", _p)]
+                ("bias", _p), ("epilogue", _i), ("aux", _p), ("res1", _p), ("res2", _p), ("beta", _f), ("colsum", _p), ("sumsq", _p)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -107,7 +109,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m mafed_amd.build` (or __graft_entry__.build()). "
             "mafed_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    loose = bool(os.environ.get("MAFED_HIP_LIB")) and os.environ.get("MAFED_HIP_LIB_LOOSE") == "1"   # tools: A/B against an older build of the library
     for name, (res, args) in SIGNATURES.items():
+        if loose and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

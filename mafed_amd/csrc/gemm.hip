@@ -666,6 +666,7 @@ extern "C" int mafed_gemm_set_variant(int v) {
 static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                      const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
                      void* aux, const float* res1, const float* res2, float beta, float* colsum, void* stream);
+extern "C" int mafed_sumsq_accumulate(const float* x, int64_t n, float* sumsq16, void* stream);   // optim.hip
 
 extern "C" int mafed_gemm(mafed_dtype in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                           const void* B, int64_t ldb, void* C, int64_t ldc, mafed_dtype c_dtype, const float* bias, int epilogue,
@@ -695,7 +696,7 @@ static bool pp_fill_problem(PPProblem& pr, bool a_ks, bool b_ks, int64_t M, int6
   // the weight-gradient instantiations (both operands reduction-major) carry the bias / beta epilogues only (PPEpilogue PLAIN_ONLY)
   if (a_ks && b_ks && (epi.mode != MAFED_EPI_NONE || r1 || r2 || colsum)) return false;
   pr.A = (const bf16_t*)A; pr.B = (const bf16_t*)B; pr.C = C;
-  pr.bias = epi.bias; pr.aux = epi.aux; pr.res1 = epi.res1; pr.res2 = epi.res2; pr.colsum = colsum;
+  pr.bias = epi.bias; pr.aux = epi.aux; pr.res1 = epi.res1; pr.res2 = epi.res2; pr.colsum = colsum; pr.sumsq = nullptr;
   pr.lda = lda; pr.ldb = ldb; pr.ldc = ldc;
   pr.beta = epi.beta; pr.mode = epi.mode; pr.res1_bf16 = epi.res1_bf16;
   pr.tiles_m = pr.tiles_n = pr.nkt = pr.tile_begin = pr.pad_ = 0;
@@ -719,12 +720,18 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
     GemmEpi epi{q.bias, q.epilogue & ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT), q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
     one = q.A && q.B && q.C && q.M > 0 && (c_dtype == MAFED_F32 || q.beta == 0.f) && !(q.colsum && q.beta != 0.f) &&
           pp_fill_problem(pr[i], a_ks, b_ks, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, epi, q.colsum);
+    // squares of the stored C: fused into the weight-gradient kernels' epilogue only (both operands reduction-major, fp32 C, not the
+    // 256 x 256 kernel); any other launch computes them in a pass over C behind the product (below)
+    if (one) pr[i].sumsq = q.sumsq;
+    if (one && q.sumsq && !(a_ks && b_ks && c_dtype == MAFED_F32)) one = false;
     Ms[i] = q.M; Ns[i] = q.N; Ks[i] = q.K; ldas[i] = q.lda; ldbs[i] = q.ldb;
   }
   if (one) {
     double fill = 0.0;
     cfg = gemm_pp_pick(a_ks, b_ks, c_dtype, n, Ms, Ns, Ks, ldas, ldbs, g_gemm_pp_force, &fill);
     one = cfg != PP_NONE && (g_gemm_pp_force >= 0 || fill >= 0.7);
+    for (int i = 0; one && i < n; ++i)
+      if (problems[i].sumsq && cfg == PP_256x256) one = false;   // (gemm_z.hip carries no fused squares)
   }
   if (one) {
     const int rc = gemm_pp_launch(cfg, a_ks, b_ks, c_dtype, pr, n, Ms, Ns, Ks, as_stream(stream));
@@ -738,6 +745,11 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
     const int rc = gemm_impl(in_dtype, transA, transB, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, q.bias, q.epilogue, q.aux, q.res1,
                              q.res2, q.beta, q.colsum, stream);
     if (rc != MAFED_OK) return rc;
+    if (q.sumsq) {
+      MAFED_CHECK_ARG(c_dtype == MAFED_F32 && q.ldc == q.N, "gemm_grouped: sumsq needs a dense fp32 C");
+      const int rc2 = mafed_sumsq_accumulate((const float*)q.C, q.M * q.N, q.sumsq, stream);
+      if (rc2 != MAFED_OK) return rc2;
+    }
   }
   return MAFED_OK;
 }

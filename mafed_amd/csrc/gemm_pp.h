@@ -5,7 +5,7 @@
 
 namespace mafed {
 
-constexpr int PP_MAXP = 16;  // problems per grouped launch (kernarg: 32 + 16 x 120 bytes)
+constexpr int PP_MAXP = 16;  // problems per grouped launch (kernarg: 32 + 16 x 128 bytes)
 constexpr int PP_TICKET_STRIDE = 16;   // dwords between the queue heads of a slot (one 64-byte line each: atomics on different heads do not share a line)
 
 // One C = op(A).op(B) problem of a (possibly grouped) persistent launch.  All problems of a launch share the operand
@@ -19,6 +19,7 @@ struct PPProblem {
   const void* res1;
   const float* res2;
   float* colsum;
+  float* sumsq;   // 16 slots or null: += squares of the stored C (weight-gradient kernels only)
   int64_t lda, ldb, ldc;
   float beta;
   int mode;       // MAFED_EPI_*

@@ -15,7 +15,7 @@
 
 namespace mafed {
 
-struct PPEpiProb { void* C; const float* bias; void* aux; const void* res1; const float* res2; float* colsum; int64_t ldc; float beta; int mode, res1_bf16, nkt; };
+struct PPEpiProb { void* C; const float* bias; void* aux; const void* res1; const float* res2; float* colsum; float* sumsq; int64_t ldc; float beta; int mode, res1_bf16, nkt; };
 
 // Column group outermost (8 columns of a bf16 C, 4 of an fp32 C: one store instruction = 16 rows x 64 bytes), row fragments inside,
 // the operands the epilogue READS (saved pre-activation of GELU', residuals, old C) fetched PD row fragments ahead of the stores.
@@ -101,6 +101,7 @@ struct PPEpilogue {
     for (int i = 0; i < PD; ++i) fetch(i, pre[i]);
     hook();
     float cs[GW];
+    float ssq = 0.f;   // PLAIN_ONLY (weight gradients): squares of what this lane stores, for the clip's norm (cq.sumsq)
 #pragma unroll
     for (int idx = 0; idx < NI; ++idx) {
       const int g = idx / MT, mt = idx % MT;
@@ -165,6 +166,7 @@ struct PPEpilogue {
         }
         if constexpr (PAIR) store8(C + o, v);
         else store4(C + o, make_float4(v[0], v[1], v[2], v[3]));
+        if constexpr (PLAIN_ONLY && !PAIR) ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         if (colsum) {
 #pragma unroll
           for (int e = 0; e < GW; ++e) cs[e] += v[e];
@@ -178,6 +180,12 @@ struct PPEpilogue {
           s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
           if (li == 0) scr[g * GSTEP + GW * q4 + e] = s;
         }
+      }
+    }
+    if constexpr (PLAIN_ONLY && !PAIR) {
+      if (cq.sumsq) {   // one float atomic per wave and tile, spread over 16 slots by (tile column, tile row)
+        ssq = wave_sum(ssq);
+        if (lane == 0) atomicAdd(cq.sumsq + (int)(((colw >> 5) + (row0 >> 7)) & 15), ssq);
       }
     }
     if (colsum) {

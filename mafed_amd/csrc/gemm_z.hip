@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_z_kernel(PPArgs args_by_value) {
   };
   auto load_cq = [&](int pi) {
     cq.C = args->p[pi].C; cq.bias = args->p[pi].bias; cq.aux = args->p[pi].aux; cq.res1 = args->p[pi].res1; cq.res2 = args->p[pi].res2;
-    cq.colsum = args->p[pi].colsum; cq.ldc = args->p[pi].ldc; cq.beta = args->p[pi].beta; cq.mode = args->p[pi].mode;
+    cq.colsum = args->p[pi].colsum; cq.sumsq = args->p[pi].sumsq; cq.ldc = args->p[pi].ldc; cq.beta = args->p[pi].beta; cq.mode = args->p[pi].mode;
     cq.res1_bf16 = args->p[pi].res1_bf16; cq.nkt = args->p[pi].nkt;
   };
   auto decode = [&](int id, int& pi, int& tm, int& tn) -> bool {

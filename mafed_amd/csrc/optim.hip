@@ -29,6 +29,23 @@ __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __re
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// sumsq16[blockIdx & 15] += sum of squares of this block's share of x (the unfused form of the weight-gradient epilogue's squares)
+__global__ __launch_bounds__(256) void sumsq_accumulate_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ sumsq16) {
+  __shared__ float sm[4];
+  const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * blockDim.x;
+  float s0 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 a = load4(x + i * 4);
+    s0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+    const float a = x[n4 * 4 + threadIdx.x];
+    s0 += a * a;
+  }
+  const float s = block_sum<256>(s0, sm);
+  if (threadIdx.x == 0) atomicAdd(sumsq16 + (blockIdx.x & 15), s);
+}
+
 __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm,
                                                               float* __restrict__ out2) {
   __shared__ float sm[4];
@@ -173,6 +190,8 @@ __global__ __launch_bounds__(256) void gradnorm_finish_advance_kernel(const floa
 
 using namespace mafed;
 
+extern "C" int mafed_gradnorm_blocks(int64_t n);
+
 extern "C" int mafed_optim_advance(int64_t* state_dev, double base_lr, int64_t warmup_steps, int64_t total_steps, double beta1,
                                    double beta2, float* hyper3_dev, void* stream) {
   MAFED_CHECK_ARG(state_dev && hyper3_dev, "optim_advance: null pointer");
@@ -188,6 +207,14 @@ extern "C" int mafed_optim_advance_guarded(int64_t* state_dev, double base_lr, i
   optim_advance_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>((long long*)state_dev, base_lr, (long long)warmup_steps,
                                                                     (long long)total_steps, beta1, beta2, hyper3_dev, clip_dev);
   MAFED_CHECK_LAUNCH("optim_advance");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_sumsq_accumulate(const float* x, int64_t n, float* sumsq16, void* stream) {
+  MAFED_CHECK_ARG(x && sumsq16 && n >= 0 && ((uintptr_t)x & 15) == 0, "sumsq_accumulate: bad arguments");
+  if (n == 0) return MAFED_OK;
+  launch(K_GRADNORM, (double)n * 4.0, sumsq_accumulate_kernel, dim3((unsigned)mafed_gradnorm_blocks(n)), dim3(256), 0, as_stream(stream), x, n, sumsq16);
+  MAFED_CHECK_LAUNCH("sumsq_accumulate");
   return MAFED_OK;
 }
 

@@ -162,6 +162,33 @@ __global__ __launch_bounds__(1024) void stream_probe_kernel(const float4* __rest
   if (acc == 1.2345e-30f && sink) sink[0] = acc;
 }
 }  // namespace mafed
+// The same AdamW-shaped sweep, wrapping around the buffer until `ticks` of the 100 MHz s_memrealtime clock have passed: a stand-in for one
+// bucket's all-reduce kernels (RCCL: one workgroup per channel, copy / reduce loops for the collective's duration).
+namespace mafed {
+__global__ __launch_bounds__(1024) void stream_for_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n16, long long ticks) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  const long long q = n16 / 4, stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // every wave reaches the exit: the loop is bounded by the wall clock (checked once per trip: ~64 bytes per lane between checks)
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    if (i >= q) i -= (i / stride) * stride;   // wrap to this thread's first element
+    float4 a = src[i], b = src[q + i], c = src[2 * q + i], d = src[3 * q + i];
+    a.x += b.x * c.x + d.x; a.y += b.y * c.y + d.y; a.z += b.z * c.z + d.z; a.w += b.w * c.w + d.w;
+    dst[i] = a; dst[q + i] = b; dst[2 * q + i] = c; dst[3 * q + i] = d;
+    i += stride;
+  }
+}
+}  // namespace mafed
+extern "C" int mafed_tune_stream_for(const void* src, void* dst, long long n_bytes, int blocks, int threads, double microseconds, void* stream) {
+  using namespace mafed;
+  MAFED_CHECK_ARG(src && dst && n_bytes >= (1 << 20) && n_bytes % 64 == 0 && blocks >= 1 && blocks <= 256 && threads >= 64 && threads <= 1024 &&
+                  threads % 64 == 0 && microseconds >= 0.0 && microseconds <= 1e6, "tune_stream_for: bad arguments");
+  MAFED_CHECK_ARG((long long)blocks * threads <= n_bytes / 64, "tune_stream_for: buffer too small for the grid");
+  stream_for_kernel<<<dim3(blocks), dim3(threads), 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst, n_bytes / 16, (long long)(microseconds * 100.0));
+  MAFED_CHECK_LAUNCH("tune_stream_for");
+  return MAFED_OK;
+}
+
 extern "C" int mafed_tune_stream(const void* src, void* dst, long long n_bytes, int blocks, int threads, int unroll, int mode, void* stream) {
   using namespace mafed;
   MAFED_CHECK_ARG(src && n_bytes >= 0 && n_bytes % 64 == 0 && blocks >= 1 && blocks <= 65536 && threads >= 64 && threads <= 1024 && threads % 64 == 0 &&

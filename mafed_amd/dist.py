@@ -199,6 +199,34 @@ class GradReducer:
         return out
 
 
+class EmulatedReducer(GradReducer):
+    """ONE-GPU stand-in for the gradient exchange of an N-GPU run (``bench.py --emulate-collectives``; no multi-GPU node was ever available
+    to this build): same buckets, same hooks, same side stream -- but instead of a collective each bucket launches
+    ``mafed_tune_stream_for``: ``channels`` workgroups that stream memory for the time an all-reduce of that bucket would take when the
+    whole 1.63 GB exchange takes ``allreduce_ms`` (~2.7 ms with all seven xGMI links busy, ~18.6 ms for a single
+    ring).  Gradients are left untouched (one rank's mean is itself).  What this prices: the CUs and the memory traffic the collective's
+    kernels take from the backward that runs beside them; what it cannot: link contention, rank skew, RCCL's own launch costs."""
+
+    def __init__(self, model, allreduce_ms: float, channels: int = 16, world: int = 8, bucket_mb: float = 64.0, buffer_mb: int = 256):
+        super().__init__(model, None, bucket_mb)
+        self.world = int(world)          # (what Trainer looks at to decide how the backward beside the collectives runs)
+        self.allreduce_ms, self.channels = float(allreduce_ms), int(channels)
+        dev = model.flat_grads.device
+        self._src = torch.empty(buffer_mb << 20, dtype=torch.uint8, device=dev)
+        self._src.view(torch.float32).normal_()
+        self._dst = torch.empty_like(self._src)
+        self._total = float(sum(hi - lo for _, (lo, hi) in self.buckets))
+
+    def _reduce_bucket(self, lo: int, hi: int):
+        from mafed_amd import _lib
+        us = self.allreduce_ms * 1e3 * (hi - lo) / self._total
+        self.bytes_per_step += (hi - lo) * 4
+        st = torch.cuda.current_stream()
+        _lib.check(_lib.load().mafed_tune_stream_for(self._src.data_ptr(), self._dst.data_ptr(), self._src.numel(), self.channels, 1024, us,
+                                                     st.cuda_stream), "tune_stream_for")
+        return [], (lambda: None)
+
+
 def broadcast_teacher(model, src: int = 0, process_group=None) -> None:
     """Once per task: every replica's frozen teacher := rank ``src``'s (1.63 GB at 410M)."""
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:

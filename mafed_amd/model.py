@@ -766,6 +766,11 @@ class VLPythiaForCausalLM(nn.Module):
             self._zero_layer_matrices(range(L))
         self._dw_stale = False
         dw_beta = 0.0 if overwrite else 1.0
+        # squares of the final matrix gradients from the weight-gradient epilogues (FlatAdamW.begin_incremental_norm): only a sweep whose
+        # products all go through the grouped call can promise them -- it records its serial, the norm hook checks it
+        dw_sq = getattr(self, "dw_sumsq", None) if (group_dw and taps is None) else None
+        self._dw_sumsq_used = self._bw_serial if dw_sq is not None else None
+        DW_SLOT = {"attention.query_key_value.weight": 0, "attention.dense.weight": 1, "mlp.dense_h_to_4h.weight": 2, "mlp.dense_4h_to_h.weight": 3}
         pending_dw: List[dict] = []
         pending_layers: List[int] = []
 
@@ -773,7 +778,11 @@ class VLPythiaForCausalLM(nn.Module):
             if not group_dw:
                 wgrad(dY, X, wname, bname)
                 return
-            pending_dw.append(dict(A=dY, B=X, out=g(wname), beta=dw_beta))
+            q = dict(A=dY, B=X, out=g(wname), beta=dw_beta)
+            if dw_sq is not None:
+                li_, kind = wname[len("gpt_neox.layers."):].split(".", 1)
+                q["sumsq"] = dw_sq[int(li_), DW_SLOT[kind]]
+            pending_dw.append(q)
             if bname is not None:
                 on_side(lambda: ops.colsum_(dY, g(bname)), dY)
 

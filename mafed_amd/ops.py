@@ -131,7 +131,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, transA: bool, transB: bool, out: Opti
 def gemm_grouped(problems, transA: bool, transB: bool) -> None:
     """Several independent ``C_i = op(A_i) @ op(B_i)`` as one persistent launch (mafed_gemm_grouped).  ``problems``: dicts with the
     keyword arguments of :func:`gemm` (``A``, ``B``, ``out`` required; ``bias``, ``epilogue``, ``aux``, ``res1``, ``res2``, ``beta``,
-    ``colsum`` optional).  All share the operand layouts, the input dtype and the output dtype."""
+    ``colsum`` optional; ``sumsq`` = 16 fp32 slots that receive += the squares of the stored fp32 C).  All share the operand layouts, the input dtype and the output dtype."""
     n = len(problems)
     if n == 0:
         return
@@ -157,6 +157,9 @@ def gemm_grouped(problems, transA: bool, transB: bool) -> None:
         g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0)
         g.bias, g.epilogue, g.aux = _ptr(q.get("bias")), epi, _ptr(q.get("aux"))
         g.res1, g.res2, g.beta, g.colsum = _ptr(res1), _ptr(q.get("res2")), float(q.get("beta", 0.0)), _ptr(cs)
+        sq = q.get("sumsq")
+        assert sq is None or (sq.dtype == torch.float32 and sq.numel() >= 16 and sq.is_contiguous() and out.dtype == torch.float32)
+        g.sumsq = _ptr(sq)
     rc = _fn.gemm_grouped(in_dt, int(transA), int(transB), out_dt, arr, n, _stream())
     if rc:
         check(rc, "mafed_gemm_grouped")

@@ -114,6 +114,13 @@ class FlatAdamW:
                         for lo, hi in trig[t]:
                             plan[t].append((lo, hi, slot))
                             slot += ops.gradnorm_blocks(hi - lo)
+                    # behind the range partials: 16 slots per layer weight matrix (4 per layer) for the squares the weight-gradient GEMMs'
+                    # epilogues leave (mafed_gemm_problem.sumsq) -- zero unless a backward uses them (begin_incremental_norm)
+                    self._norm_dw_lo = slot
+                    has_mat = hasattr(self.model, "layer_matrix_range") and all(
+                        per_layer[i][0] <= self.model.layer_matrix_range(i)[0] and self.model.layer_matrix_range(i)[1] == per_layer[i][1] for i in range(L))
+                    self._norm_dw_n = 16 * 4 * L if has_mat else 0
+                    slot += self._norm_dw_n
                     self._norm_slots = slot
                     self._norm_partials = torch.zeros(slot, dtype=torch.float32, device=self.model.flat_grads.device)
             except Exception:
@@ -121,19 +128,34 @@ class FlatAdamW:
             self._norm_plan_cache = plan
         return self._norm_plan_cache
 
-    def begin_incremental_norm(self):
+    def begin_incremental_norm(self, fused_matrix_squares: bool = False):
         """-> hook(i) for ``model.grad_ready_hook`` (or None): called by the backward on the stream that finished range i, it
         launches that range's sum-of-squares partials at once -- under the rest of the backward -- so that ``clip_grad_norm_`` only
-        has the finish kernel left (the one-pass norm reads 1.6 GB on the optimiser step's critical path: 0.28 ms at 410M)."""
+        has the finish kernel left (the one-pass norm reads 1.6 GB on the optimiser step's critical path: 0.28 ms at 410M).
+        ``fused_matrix_squares``: the grouped weight-gradient GEMMs of THIS backward leave the squares of the layers' matrix gradients in
+        ``model.dw_sumsq`` slots (their epilogues hold the final values in registers); the hook then reads only a layer's LayerNorm
+        weights -- 1.2 GB of the 1.63 GB pass gone.  The model clears ``dw_sumsq`` when a sweep could not use it (then the hook reads
+        the whole range, as before)."""
         plan = self._norm_plan()
         self._norm_seen = {}
         if plan is None:
             return None
         g, part, model = self.model.flat_grads, self._norm_partials, self.model
+        L = model.config.num_hidden_layers
+        n_dw = getattr(self, "_norm_dw_n", 0)
+        if n_dw:
+            part[self._norm_dw_lo:].zero_()
+        model.dw_sumsq = part[self._norm_dw_lo:self._norm_dw_lo + n_dw].view(L, 4, 16) if (fused_matrix_squares and n_dw) else None
 
         def hook(i):
+            fused = model.dw_sumsq is not None and 0 <= i < L and getattr(model, "_dw_sumsq_used", None) == getattr(model, "_bw_serial", 0)
             for lo, hi, slot in plan.get(i, ()):
-                ops.gradnorm_partial(g[lo:hi], part[slot:])
+                if fused:
+                    hi = model.layer_matrix_range(i)[0]   # the LayerNorm weights in front of the matrices; the matrices' squares are in dw_sumsq
+                if hi > lo:
+                    ops.gradnorm_partial(g[lo:hi], part[slot:])
+            if self._norm_seen is None:     # a backward outside Trainer.step() while the hook is still installed (clip_grad_norm_ consumed the
+                self._norm_seen = {}        # last window's record): its partials are simply never used
             self._norm_seen[i] = getattr(model, "_bw_serial", 0)   # which backward sweep this range's partials belong to
         hook.is_norm_hook = True   # Trainer replaces / removes hooks of this kind only
         return hook

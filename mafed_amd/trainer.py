@@ -29,7 +29,7 @@ class Trainer:
     def __init__(self, model, cl_method, config: Optional[Any] = None, task_id: int = 0, n_batches_per_epoch: int = 1000,
                  process_group=None, ddp: bool = False, bucket_mb: float = 64.0, pipeline_optimizer: bool = False,
                  grad_dtype: Optional[torch.dtype] = None, reduce_mode: str = "all_reduce", incremental_norm: bool = True,
-                 overwrite_weight_grads: bool = True):
+                 overwrite_weight_grads: bool = True, reducer=None):
         cfg = config if config is not None else SimpleNamespace()
         self.config = cfg
         self.model = model
@@ -47,7 +47,8 @@ class Trainer:
                                      getattr(cfg, "warmup_steps", None))
         total = int(getattr(cfg, "total_steps", total))
         self.scheduler = get_linear_schedule_with_warmup(self.optimizer, warm, total, last_epoch=-1)
-        self.reducer = GradReducer(model, process_group, bucket_mb, grad_dtype=grad_dtype, mode=reduce_mode) if ddp else None
+        # (``reducer``: a ready-made GradReducer, e.g. dist.EmulatedReducer -- the one-GPU forecast of the N-GPU step)
+        self.reducer = reducer if reducer is not None else (GradReducer(model, process_group, bucket_mb, grad_dtype=grad_dtype, mode=reduce_mode) if ddp else None)
         # AdamW + gradient zeroing chunk by chunk on their own stream, the next forward waiting per layer (FlatAdamW.
         # apply_pipelined).  Opt-in: between step() calls the caller's stream may then only reach the parameters through the
         # model's forward, or after join().
@@ -61,6 +62,8 @@ class Trainer:
         # written by the optimiser pass and 1.2 GB less read by the weight-gradient epilogues per step at 410M.  Single process, grouped
         # bf16 weight gradients only (`_overwrite_ok`); after a step the matrices' ``.grad`` holds the last gradient, not zeros.
         self.overwrite_weight_grads = bool(overwrite_weight_grads)
+        # the clip's norm of the layers' weight matrices from the weight-gradient GEMMs' own epilogues (FlatAdamW.begin_incremental_norm)
+        self.fused_norm_squares = True
         self.global_step = 0
         self._one = None
         self.optimizer.zero_grad()
@@ -111,7 +114,9 @@ class Trainer:
         if self.reducer is None and hasattr(self.model, "grad_ready_hook"):
             cur = self.model.grad_ready_hook
             if cur is None or getattr(cur, "is_norm_hook", False):   # (a hook installed by somebody else is left alone)
-                self.model.grad_ready_hook = self.optimizer.begin_incremental_norm() if inc_norm else None
+                self.model.grad_ready_hook = self.optimizer.begin_incremental_norm(fused_matrix_squares=self.fused_norm_squares) if inc_norm else None
+                if not inc_norm and hasattr(self.model, "dw_sumsq"):
+                    self.model.dw_sumsq = None
             else:
                 self.optimizer._norm_seen = None
         ow = self._overwrite_ok()

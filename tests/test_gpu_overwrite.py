@@ -150,3 +150,70 @@ def test_non_finite_gradient_norm_skips_the_update():
         torch.cuda.synchronize()
         assert torch.isfinite(rec["grad_norm"]).item() and int(tr.optimizer.state_dev) == 2
         assert torch.isfinite(student.flat_params).all()
+
+
+# ---- squares of the weight gradients from the GEMM epilogue (mafed_gemm_problem.sumsq) ---------------------------------------------
+@pytest.mark.parametrize("shape", [(1024, 1024, 4608), (3072, 1024, 2304), (192, 64, 96)])
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_grouped_gemm_leaves_the_squares_of_c(shape, beta):
+    """sum of the 16 slots += sum C^2 of the stored C: fused into the persistent weight-gradient kernel where the shapes tile it
+    (first two), a pass over C behind the product otherwise (third)."""
+    from mafed_amd import ops
+    M, N, K = shape
+    g = torch.Generator(device=DEV).manual_seed(5)
+    probs = []
+    for i in range(2):
+        A = (torch.randn(K, M, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+        B = (torch.randn(K, N, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+        out = torch.randn(M, N, device=DEV, generator=g)
+        probs.append(dict(A=A, B=B, out=out, beta=beta, sumsq=torch.full((16,), 0.5 * i, device=DEV)))
+    ops.gemm_grouped(probs, True, False)
+    torch.cuda.synchronize()
+    for i, q in enumerate(probs):
+        want = float((q["out"].double() ** 2).sum()) + 16 * 0.5 * i
+        got = float(q["sumsq"].double().sum())
+        assert abs(got - want) <= 1e-5 * want, (shape, beta, i, got, want)
+
+
+@pytest.mark.timeout(600)
+def test_fused_norm_squares_give_the_same_clip_norm_at_410m():
+    """Trainer(fused_norm_squares) at the benchmark's size and configuration: the norm the clip sees == the norm of the range partials
+    == the one-pass norm, step by step."""
+    from mafed_amd import FeatureDistillation, Trainer, VLPythiaConfig, VLPythiaForCausalLM
+    from mafed_amd.methods import HBMReplayBuffer
+    B, P, T = 32, 256, 32
+    cfg = VLPythiaConfig.preset("410m", num_vision_tokens=P)
+    gcpu = torch.Generator().manual_seed(1235)
+    ids = torch.randint(1, cfg.vocab_size, (64, T), generator=gcpu)
+    labels = torch.full((64, T), -100, dtype=torch.int64)
+    labels[:, -4:] = ids[:, -4:]
+    feats = torch.randn(64, P, cfg.vision_hidden_size, generator=gcpu).to(torch.bfloat16)
+    samples = {"input_ids": ids, "attention_mask": torch.ones(64, T, dtype=torch.int64), "labels": labels, "patch_embeddings": feats}
+    norms = {}
+    for mode in ("fused", "partials", "onepass"):
+        student = VLPythiaForCausalLM(cfg, compute_dtype=torch.bfloat16, device=DEV, seed=1234)
+        opts = types.SimpleNamespace(tasks=["t0", "t1"], batch_size=B, seed=1236, pin_mem=False, accumulate_grad_batches=1)
+        fd = FeatureDistillation(memory_size=4000, opts=opts, model_type="vlpythia", num_hidden_layers=cfg.num_hidden_layers - 1,
+                                 distillation_modality_weighing_strategy="balanced", distillation_layer_weighing_strategy="discounted",
+                                 gamma=0.5, distillation_layer=None)
+        fd._update_model(student)
+        gen = torch.Generator(device=DEV).manual_seed(1237)
+        fd.past_model.flat_params.add_(torch.randn(fd.past_model.flat_params.shape, generator=gen, device=DEV) * 1e-3)
+        fd.past_model._shadow_dirty = True
+        fd.task_id, fd.num_vision_tokens = 1, P
+        mem = HBMReplayBuffer(B, torch.device(DEV), seed=9)
+        mem.add(samples)
+        fd.mem_dataloader = mem
+        tr = Trainer(student, fd, _conf(lr=5e-5), task_id=1, pipeline_optimizer=True, incremental_norm=mode != "onepass")
+        tr.fused_norm_squares = mode == "fused"
+        task_batch = mem.sample()
+        norms[mode] = [float(tr.step(task_batch, i)["grad_norm"]) for i in range(3)]
+        tr.join()
+        torch.cuda.synchronize()
+        if mode == "fused":
+            assert student.dw_sumsq is not None and student._dw_sumsq_used == student._bw_serial
+        del tr, fd, student, mem
+        torch.cuda.empty_cache()
+    for a, b, c in zip(norms["fused"], norms["partials"], norms["onepass"]):
+        assert abs(a - c) <= 2e-3 * c and abs(b - c) <= 2e-3 * c, norms   # (2e-3: the run-to-run noise of a bf16 backward's atomics)
+    assert abs(norms["fused"][0] - norms["partials"][0]) <= 2e-3 * norms["partials"][0]

@@ -238,7 +238,9 @@ def test_clip_norm_plan_tiles_the_gradient_buffer():
         for lo, hi, s in order:
             assert s == slot
             slot += ops.gradnorm_blocks(hi - lo)
-        assert slot == opt._norm_slots == opt._norm_partials.numel()
+        # (behind the range partials: 16 slots per layer weight matrix for the squares the weight-gradient epilogues leave)
+        assert slot == opt._norm_dw_lo and opt._norm_dw_n == 16 * 4 * L
+        assert slot + opt._norm_dw_n == opt._norm_slots == opt._norm_partials.numel()
 
 
 def test_clip_tower_row_padding_minimises_tile_rounds():
