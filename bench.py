@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--exact-normaliser", action="store_true", help="N > 1: distillation means over the GLOBAL token counts (one small all-reduce)")
     ap.add_argument("--no-ddp-forecast", action="store_true", help="N = 1: skip the emulated-collectives leg (`ddp_forecast` key)")
     ap.add_argument("--emulate-channels", type=int, default=16, help="N = 1 forecast: workgroups of the stand-in collective kernel (RCCL channels)")
-    ap.add_argument("--no-ticketed-order", action="store_true", help="persistent GEMM kernels in the static tile order of round 3 (A/B)")
+    ap.add_argument("--tile-order", default="auto", choices=["auto", "static", "ticketed"], help="persistent GEMM kernels: auto = per call (static "
+                    "on a free chip, ticketed for the backward beside collectives), static / ticketed = everywhere (A/B)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -233,9 +234,9 @@ def main():
     if args.gemm_variant is not None:
         from mafed_amd import _lib
         _lib.load().mafed_gemm_set_variant(args.gemm_variant)
-    if args.no_ticketed_order:
+    if args.tile_order != "auto":
         from mafed_amd import _lib
-        _lib.load().mafed_gemm_set_variant(720)
+        _lib.load().mafed_gemm_set_variant(720 if args.tile_order == "static" else 721)
     rank, local, world = init_from_env()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
@@ -282,7 +283,7 @@ def main():
         student.dw_group_layers = args.dw_group_layers
     fd.exact_normaliser = bool(args.exact_normaliser)
     if args.contended_backward:
-        student.contended_backward = True
+        student.contended_backward = "128x128"
     # the replay memory holds --memory-size samples (the reference's memory_size = 4000, scripts/run_seed42.sh) resident in HBM: bf16 patch
     # features [n, P, dv] (2.1 GB at 4000 x 256 x 1024) + int64 text tensors; generated on the device in chunks, rank-specific seeds
     n_mem = max(8 * B, args.memory_size)
@@ -307,7 +308,7 @@ def main():
     tr = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, ddp=world > 1, pipeline_optimizer=not args.no_pipeline_optimizer,
                  bucket_mb=args.bucket_mb, reduce_mode=args.reduce_mode, grad_dtype=gdt, incremental_norm=not args.no_incremental_norm)
     if args.gemm_variant is not None:
-        tr.contention_aware = False   # an explicit kernel choice is not overridden under N > 1
+        tr.contention_mode = None   # an explicit kernel choice is not overridden under N > 1
     task_batch = mem.sample()  # dropped by a replay step, as in the reference
 
     def barrier():
@@ -402,12 +403,12 @@ def main():
         rows = []
         n_f = max(5, args.steps // 2)
         for ar_ms in (2.7, 18.6):
-            for mode in ("persistent_ticketed", "128x128"):
+            for mode in ("persistent_ticketed", "persistent_static", "128x128"):
                 student.zero_grad()
                 red = EmulatedReducer(student, ar_ms, channels=args.emulate_channels, bucket_mb=args.bucket_mb)
                 trf = Trainer(student, fd, conf, task_id=1, n_batches_per_epoch=1000, pipeline_optimizer=not args.no_pipeline_optimizer,
                               incremental_norm=not args.no_incremental_norm, reducer=red)
-                trf.contention_aware = mode == "128x128"
+                trf.contention_mode = {"persistent_ticketed": "ticketed", "persistent_static": None, "128x128": "128x128"}[mode]
                 for i in range(3):
                     trf.step(task_batch, 20_000 + i)
                 torch.cuda.synchronize()
@@ -650,7 +651,7 @@ def main():
                           "global_batch": B * world, "per_gpu_batch": B, "seq_len": P + T, "parallelism": f"dp{world}",
                           "random_init_weights": True},
                "ranks_joined": ranks_joined, "dist_backend": backend, "runtime_env": runtime_env(),
-               "gemm_tile_order": "static" if args.no_ticketed_order else "ticketed",
+               "gemm_tile_order": {"auto": "per call: static on a free chip, ticketed beside collectives"}.get(args.tile_order, args.tile_order),
                "replay_memory": {"samples": len(mem), "HBM_MB": round(sum(v.numel() * v.element_size() for v in mem.data.values() if v is not None) / 1e6, 1)},
                "step_tflops_algorithmic": round(flops_step / 1e12, 3),
                "mfma_frac_whole_step": round(flops_exec * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(loss, 5),

@@ -40,8 +40,11 @@ enum {
   MAFED_EPI_GELU_BWD = 2, /* C = (acc) * gelu_erf'(aux) ; aux = saved pre-activation, same dtype as C */
   MAFED_EPI_QUICK_GELU = 3, /* C = x * sigmoid(1.702 x), x = acc + bias: MLP activation of the frozen CLIP vision tower (clip:338-350) */
   MAFED_EPI_RES1_BF16 = 0x100, /* flag, OR-ed in: res1 points at bf16 data (the attention branch output under bf16 autocast) */
-  MAFED_EPI_NO_PERSISTENT = 0x200 /* flag, OR-ed in: THIS call keeps off the one-block-per-CU persistent kernels (a product that runs beside a
-                                     long-resident kernel of another stream, e.g. a collective); per call, no process-wide state */
+  MAFED_EPI_NO_PERSISTENT = 0x200, /* flag, OR-ed in: THIS call keeps off the one-block-per-CU persistent kernels (a product that runs beside a
+                                      long-resident kernel of another stream, e.g. a collective); per call, no process-wide state */
+  MAFED_EPI_TICKETED = 0x400 /* flag, OR-ed in: if THIS call takes a persistent kernel over more than one round of the CUs, the blocks draw
+                                their tiles from per-XCD queues instead of walking a static schedule (tolerates CUs held by other streams'
+                                kernels: 1.2 - 1.3x instead of 1.7 - 1.9x with 8 - 32 CUs taken; costs a free chip ~2 %) */
 };
 
 int mafed_version(void);
@@ -349,8 +352,9 @@ const char* mafed_prof_tag_name(int tag);
  * 10 + c = force LDS-DMA tile configuration c; 100 = automatic split-K for accumulate-only outputs, 101 = no split-K,
  * 100 + n = force n K-splits where legal */
 int mafed_gemm_set_variant(int variant);
-/* 720 = the persistent kernels walk their tiles in the static order (tile = round x grid + slot), 721 = ticketed order (default): a
- * block's first tile is static, every further one is drawn from a per-XCD queue, so a launch tolerates CUs held by other streams' kernels.
+/* 720 = the persistent kernels walk their tiles in the static order (tile = round x grid + slot) whatever the call says, 721 = ticketed
+ * order for every multi-round launch (a block's first tile is static, every further one is drawn from a per-XCD queue), 722 = per call
+ * (MAFED_EPI_TICKETED; default).
  * mafed_gemm_get_variant reads the hooks back (which = 0: the tile-configuration variant, 7: the persistent-kernel mode 700 / 701 /
  * 710 + c, 72: 720 / 721, 73: launches that ran in ticketed order so far), so that a caller that changes one for a measurement can
  * restore what was set before */

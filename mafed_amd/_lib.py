@@ -15,6 +15,7 @@ F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QUICK_GELU = 0, 1, 2, 3
 EPI_RES1_BF16 = 0x100
 EPI_NO_PERSISTENT = 0x200
+EPI_TICKETED = 0x400
 
 _p, _i, _l, _f, _z, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 

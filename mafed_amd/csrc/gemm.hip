@@ -651,7 +651,7 @@ extern "C" int mafed_gemm_get_variant(int which) {   // which: 0 = tile-configur
   return g_gemm_variant;
 }
 extern "C" int mafed_gemm_set_variant(int v) {
-  if (v == 720 || v == 721) { gemm_pp_set_ticket_mode(v - 720); return MAFED_OK; }   // persistent kernels: static / ticketed tile order
+  if (v >= 720 && v <= 722) { gemm_pp_set_ticket_mode(v - 720); return MAFED_OK; }   // persistent kernels: static / ticketed tile order / per call
   if (v >= 700 && v < 800) { g_gemm_pp = v == 700 ? 0 : 1; g_gemm_pp_force = v >= 710 ? v - 710 : -1; return MAFED_OK; }
   if (v >= 600) { g_skinny_wide = v == 699 ? -1 : v - 600; return MAFED_OK; }
   if (v >= 500) { g_skinny_ns = v - 500; return MAFED_OK; }
@@ -710,6 +710,8 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
   MAFED_CHECK_ARG(problems && n >= 1, "gemm_grouped: no problems");
   bool one = in_dtype == MAFED_BF16 && n <= PP_MAXP && ((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0);
   for (int i = 0; one && i < n; ++i) one = !(problems[i].epilogue & MAFED_EPI_NO_PERSISTENT);   // per-call opt-out (mafed_hip.h)
+  bool want_tickets = false;
+  for (int i = 0; i < n; ++i) want_tickets = want_tickets || (problems[i].epilogue & MAFED_EPI_TICKETED) != 0;
   const bool a_ks = transA != 0, b_ks = transB == 0;
   PPProblem pr[PP_MAXP];
   int64_t Ms[PP_MAXP], Ns[PP_MAXP], Ks[PP_MAXP], ldas[PP_MAXP], ldbs[PP_MAXP];
@@ -717,7 +719,7 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
   for (int i = 0; one && i < n; ++i) {
     const mafed_gemm_problem& q = problems[i];
     const int res1_bf16 = (q.epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
-    GemmEpi epi{q.bias, q.epilogue & ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT), q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
+    GemmEpi epi{q.bias, q.epilogue & ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT | MAFED_EPI_TICKETED), q.aux, q.res1, q.res2, res1_bf16, q.beta, q.ldc, nullptr};
     one = q.A && q.B && q.C && q.M > 0 && (c_dtype == MAFED_F32 || q.beta == 0.f) && !(q.colsum && q.beta != 0.f) &&
           pp_fill_problem(pr[i], a_ks, b_ks, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, c_dtype, epi, q.colsum);
     // squares of the stored C: fused into the weight-gradient kernels' epilogue only (both operands reduction-major, fp32 C, not the
@@ -734,7 +736,7 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
       if (problems[i].sumsq && cfg == PP_256x256) one = false;   // (gemm_z.hip carries no fused squares)
   }
   if (one) {
-    const int rc = gemm_pp_launch(cfg, a_ks, b_ks, c_dtype, pr, n, Ms, Ns, Ks, as_stream(stream));
+    const int rc = gemm_pp_launch(cfg, a_ks, b_ks, c_dtype, pr, n, Ms, Ns, Ks, as_stream(stream), want_tickets);
     if (rc != MAFED_OK) return rc;
     MAFED_CHECK_LAUNCH("gemm_grouped(ping-pong)");
     ++g_gemm_pp_launches;
@@ -764,7 +766,8 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
   MAFED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
   const int res1_bf16 = (epilogue & MAFED_EPI_RES1_BF16) ? 1 : 0;
   const bool no_persistent = (epilogue & MAFED_EPI_NO_PERSISTENT) != 0;   // this call only: stay off the one-block-per-CU kernels
-  epilogue &= ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT);
+  const bool want_tickets = (epilogue & MAFED_EPI_TICKETED) != 0;          // this call only: persistent kernel in ticketed tile order
+  epilogue &= ~(MAFED_EPI_RES1_BF16 | MAFED_EPI_NO_PERSISTENT | MAFED_EPI_TICKETED);
   MAFED_CHECK_ARG(epilogue >= MAFED_EPI_NONE && epilogue <= MAFED_EPI_QUICK_GELU, "gemm: unknown epilogue %d", epilogue);
   MAFED_CHECK_ARG(epilogue != MAFED_EPI_GELU_BWD || aux, "gemm: GELU_BWD epilogue needs aux");
   MAFED_CHECK_ARG(beta == 0.f || c_dtype == MAFED_F32, "gemm: beta != 0 requires an fp32 C");
@@ -814,7 +817,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
       // 82.5 us against 78.5 for the whole product, at any prefetch depth (3 / 8 / 12 items: 82.4 / 83.0 / 82.4 us)
       if (pcfg != PP_NONE && g_gemm_pp_force < 0 && c_dtype == MAFED_F32 && epi.res1 && epi.res2) pcfg = PP_NONE;
       if (pcfg != PP_NONE) {
-        rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st);
+        rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st, want_tickets);
         if (rc != MAFED_OK) return rc;
         MAFED_CHECK_LAUNCH("gemm(bf16, ping-pong)");
         ++g_gemm_pp_launches;

@@ -31,7 +31,7 @@ struct PPProblem {
 };
 
 struct PPArgs {
-  int nprobs, ntiles, group_m, pad_;
+  int nprobs, ntiles, group_m, grid;   // grid = number of workgroups of the launch
   // dynamic tile order (gemm_pp.hip "ticketed order"): eight per-XCD queue heads of THIS launch (16 dwords apart; NULL = static order) and the
   // heads of the stream's other slot, which block 0 clears for the next ticketed launch on the same stream
   unsigned* tickets;
@@ -48,12 +48,12 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t
                  const int64_t* ldbs, int force_cfg, double* fill_out);
 // launches `n` problems (same layouts / output type / configuration) as ONE persistent grid
 int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,
-                   const int64_t* Ks, hipStream_t st);
+                   const int64_t* Ks, hipStream_t st, bool want_tickets = false);
 
 // CUs of the current device (grid of the persistent kernels, the dispatcher's fill estimate)
 int gemm_pp_num_cus();
-// ticketed tile order on (default) / off (mafed_gemm_set_variant 721 / 720)
-void gemm_pp_set_ticket_mode(int on);
+// tile order of the persistent launches: 0 static everywhere, 1 ticketed everywhere, 2 per call (default) -- mafed_gemm_set_variant 720 / 721 / 722
+void gemm_pp_set_ticket_mode(int mode);
 int gemm_pp_ticket_mode();
 int gemm_pp_ticket_launches();
 

@@ -89,7 +89,10 @@ __device__ __forceinline__ int pp_f2(int k) { return ((k >> 1) & 1) | (((k >> 3)
 //  and is the kernel gemm_pp_kernel_w without the cap; amdgpu_num_vgpr takes a literal, hence two kernels around one body)
 
 // MT x NT fragments of 16 x 16 per wave (wave tile MT*16 x NT*16, block tile MT*16 x 8*NT*16), NPH phases per K-tile, NSTG stages.
-template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
+// TK: the ticketed tile order is compiled in (gemm_pp_kernel_t / gemm_pp_kernel_w); TK = false is the static-order kernel without a
+// single instruction of it (round 4: with the ticket code compiled in but switched off at run time the multi-tile products were 4 - 7 %
+// slower than round 3's kernel in a same-box A/B -- code that is never executed still moves the compiler's wait counts and spills).
+template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT, bool TK>
 __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
   constexpr int TM = MT * 16, TN = 8 * NT * 16;
   constexpr int MTP = MT / NPH;                 // A row fragments per phase
@@ -194,9 +197,10 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
 
   // ---- tile space ---------------------------------------------------------------------------------------------------------
   const int G = (int)gridDim.x, ntiles = args->ntiles;
+  unsigned* const tk_heads = TK ? args->tickets : nullptr;
+  unsigned* const tk_clear = TK ? args->tickets_clear : nullptr;
   // ticketed order (header comment): heads of this launch's eight queues, or NULL = static order (host: single round, capture, no slot)
-  unsigned* const tk_heads = args->tickets;
-  const bool dyn = tk_heads != nullptr;
+  const bool dyn = TK && tk_heads != nullptr;
   const int tk_per = G >> 3, tk_q = (int)blockIdx.x & 7;
   int* const tk_lds = reinterpret_cast<int*>(smem + NSTG * STAGE + 2048 + PP_TRACE_BYTES);
   const uint32_t tk_lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)tk_lds;
@@ -216,10 +220,16 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
   // TK_SYNC (the weight-gradient kernel: 144 K-tiles per tile, and no register to give away): the same atomic with its own vmcnt(0) in
   // the statement, parked at once -- a microsecond per 160-us tile.
   constexpr bool TK_SYNC = A_KS && B_KS;
+#ifndef MAFED_PP_TK_RELAX
+#define MAFED_PP_TK_RELAX 1
+#endif
+  constexpr bool TK_RELAX = TK && MAFED_PP_TK_RELAX != 0 && NPH == 3 && TKW >= 2 && !TK_SYNC;   // (the first wait behind an epilogue spares the ticket atomic too)
   auto tk_issue = [&]() {
+    if constexpr (!TK) return;
     unsigned long long sav;
     const unsigned off = (unsigned)(tk_q * PP_TICKET_STRIDE * 4), one = 1u;
-    if constexpr (!TK_SYNC) {
+    if constexpr (!TK) {
+    } else if constexpr (!TK_SYNC) {
       // (s_nop 4: the queue base may come straight from a v_readlane of a spilled SGPR -- VALU-written SGPR -> VMEM address, 5 wait states)
       asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
                    : "=&s"(sav)
@@ -234,16 +244,25 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
       if (lane == 0) *tk_lds = v;
     }
   };
-  auto tk_park = [&]() {   // lane 0's value (landed: see above) -> LDS; a compiler-visible store, so that hipcc's lgkmcnt counts include it
-    if constexpr (!TK_SYNC) {
-      int v;
-      asm volatile("v_mov_b32 %0, v255" : "=v"(v));
-      if (lane == 0) *tk_lds = v;
+  // Park: lane 0's value (landed: see above) -> LDS, as ONE asm statement with its own lgkmcnt(0).  A compiler-visible store inside the
+  // K loop (round 4, first version) made hipcc merge "store pending / not pending" at the join behind the branch and tighten the counted
+  // lgkmcnt waits of EVERY K-tile: +5 % on the three-tile products with the branch never taken (same-box A/B, static order).  The
+  // statement leaves no LDS operation outstanding, so the compiler's own counts stay on the safe side; the reads it flushes were issued
+  // an interval ago.
+  auto tk_park = [&]() {
+    if constexpr (TK && !TK_SYNC) {
+      unsigned long long sav;
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, v255\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %0"
+                   : "=&s"(sav) : "v"(tk_lds_addr) : "memory");
     }
   };
-  if (dyn && blockIdx.x == 0 && wave == 0 && lane < 8 && args->tickets_clear)
-    __hip_atomic_store(args->tickets_clear + lane * PP_TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tk_wave) tk_issue();   // the block's second tile: oldest operation of the wave, complete behind the prologue's wait
+  if constexpr (TK) {
+    if (dyn && blockIdx.x == 0 && wave == 0 && lane < 8 && tk_clear)
+      __hip_atomic_store(tk_clear + lane * PP_TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if constexpr (TK) {
+    if (tk_wave) tk_issue();   // the block's second tile: oldest operation of the wave, complete behind the prologue's wait
+  }
   int slot;
   {
     const int b = (int)blockIdx.x, q = G >> 3, r = G & 7, x = b & 7;   // bijective XCD remap (cdna_hip_programming T1)
@@ -462,9 +481,11 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
   auto seg_load = [&](auto stage_c, int p, int set, int post, bool last) {
     constexpr int S = decltype(stage_c)::value;
     const int so_c = NSTG == 2 ? S * STAGE : st0, so_n = NSTG == 2 ? (S ^ 1) * STAGE : st1;
-    // ticket park: the interval after the first wait behind an epilogue (slot 1 with three phases, slot 0 with two), in front of this
-    // interval's fragment reads (the counted lgkmcnt waits below cover "all but the youngest reads")
-    if (post == 1 && p == (NPH == 3 ? 2 : 1) && tk_wave) { tk_park(); __builtin_amdgcn_sched_barrier(0); }
+    // ticket park: the interval after the first wait that covers the atomic (slot 2 of the first K-tile behind an epilogue -> slot 0 of
+    // the second), in front of this interval's fragment reads (the counted lgkmcnt waits below cover "all but the youngest reads")
+    if constexpr (TK) {
+      if ((TK_RELAX ? (post == 2 && p == 0) : (post == 1 && p == (NPH == 3 ? 2 : 1))) && tk_wave) { tk_park(); __builtin_amdgcn_sched_barrier(0); }
+    }
     if (p + 1 < NPH) {
       read_a(smem + so_c, p + 1, fa[set ^ 1]);
     } else if (!last) {
@@ -479,7 +500,13 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
       //  group 2 is a single piece)
       if (p == 1) {
         if (TM % 64 == 0 || wave < 2) { if (post == 1) pp_wait_vmcnt<(5 + NST > 63 ? 63 : 5 + NST)>(); else pp_wait_vmcnt<5>(); }
-        else { if (post == 1) pp_wait_vmcnt<(4 + NST > 63 ? 63 : 4 + NST)>(); else pp_wait_vmcnt<4>(); }
+        else {
+          // (the ticket wave -- wave 7, in this branch -- tolerates ONE more operation here: its ticket atomic sits in the queue just in
+          //  front of the epilogue's stores, and what this wait has to cover is older than it; the atomic then has until the wait of
+          //  slot 2 -- the epilogue plus two intervals, ~1.7 us with the shortest epilogue -- before it can hold the wave up)
+          if (post == 1) { if (tk_wave && TK_RELAX) pp_wait_vmcnt<(5 + NST > 63 ? 63 : 5 + NST)>(); else pp_wait_vmcnt<(4 + NST > 63 ? 63 : 4 + NST)>(); }
+          else pp_wait_vmcnt<4>();
+        }
       }
       if (p == 2) pp_wait_vmcnt<5>();
     } else {
@@ -531,7 +558,7 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
   auto epilogue = [&](int tm, int tn) {
     const bool draw = tk_wave && has_next;   // (wave-uniform: the ticket wave of a block that has a further tile)
     PPEpilogue<MT, NT, CT, false, (A_KS && B_KS)>::run(acc, cq, (int64_t)tm * TM + li, (int64_t)tn * TN + wave * NT * 16, lane,
-                                reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64, [&]() { if (draw) tk_issue(); });
+                                reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 64, [&]() { if constexpr (TK) { if (draw) tk_issue(); } });
   };
 
   // ---- main ----------------------------------------------------------------------------------------------------------------
@@ -556,7 +583,9 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
     dma_group(2 * STAGE, 0);
     pp_wait_vmcnt<9>();
   }
-  if (tk_wave) tk_park();   // (landed: the atomic is older than every piece the wait above covers)
+  if constexpr (TK) {
+    if (tk_wave) tk_park();   // (landed: the atomic is older than every piece the wait above covers)
+  }
   __builtin_amdgcn_s_barrier();
   abl_dma_on = false;
   bool first = true;
@@ -570,12 +599,23 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
     // phase 0's fragments (K-tile 0 of this tile landed and was published before the previous tile's last barrier / the prologue's)
     read_b(smem + (NSTG == 2 ? 0 : st0), fb[0]);
     read_a(smem + (NSTG == 2 ? 0 : st0), 0, fa[0]);
+#ifdef MAFED_PP_ALIGN
+    // tuning: start of the K loops on a 64-byte boundary (+ MAFED_PP_ALIGN_PAD dwords): the loop is a hand-scheduled stream of asm
+    // statements -- does its placement matter (MI355X_MICROARCH "Two waves per SIMD" item 8)?
+#define PP_ALIGN_STR2(x) #x
+#define PP_ALIGN_STR(x) PP_ALIGN_STR2(x)
+#define PP_LOOP_ALIGN() asm volatile(".p2align 6\n\t.rept " PP_ALIGN_STR(MAFED_PP_ALIGN_PAD) "\n\ts_nop 0\n\t.endr")
+#else
+#define PP_LOOP_ALIGN() do { } while (0)
+#endif
     if (grp == 0) {
+      PP_LOOP_ALIGN();
       for (int kt = 0; kt < nkt; kt += 2) {
         ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, (!first && kt == 0) ? 1 : 0, false);
         ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, (!first && kt == 0) ? 2 : 0, kt + 2 >= nkt);
       }
     } else {
+      PP_LOOP_ALIGN();
       for (int kt = 0; kt < nkt; kt += 2) {
         ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, (!first && kt == 0) ? 1 : 0, false);
         ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, (!first && kt == 0) ? 2 : 0, kt + 2 >= nkt);
@@ -584,7 +624,7 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
     trace_event(1);
     // (ticket for the tile after next: drawn inside the epilogue, parked in the first K-tile of the next tile)
     if (!(MAFED_PP_ABL == 5 || MAFED_PP_ABL == 7) || !has_next) epilogue(tm, tn);
-    else if (tk_wave) tk_issue();
+    else if (TK && tk_wave) tk_issue();
     trace_event(2);
     first = false;
     if (!has_next) break;
@@ -606,15 +646,22 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
 #endif
 }
 
+// static tile order: round 3's kernel (no register cap below 256, no ticket code)
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2))) void gemm_pp_kernel(PPArgs args_by_value) {
-  static_assert(!(A_KS && B_KS), "the weight-gradient layout runs as gemm_pp_kernel_w");
-  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT>(args_by_value);
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void gemm_pp_kernel(PPArgs args_by_value) {
+  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT, false>(args_by_value);
 }
+// ticketed tile order, asynchronous draw: v252 - v255 are kept from the compiler (PP_VGPR_CAP), the atomic lands in v255
+template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(PP_VGPR_CAP / 2))) void gemm_pp_kernel_t(PPArgs args_by_value) {
+  static_assert(!(A_KS && B_KS), "the weight-gradient layout draws synchronously: gemm_pp_kernel_w");
+  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT, true>(args_by_value);
+}
+// ticketed tile order, synchronous draw (the weight-gradient layout: no register to give away, 144 K-tiles per tile)
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void gemm_pp_kernel_w(PPArgs args_by_value) {
   static_assert(A_KS && B_KS, "synchronous tickets, no register cap: the weight-gradient layout only");
-  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT>(args_by_value);
+  gemm_pp_body<MT, NT, NPH, NSTG, A_KS, B_KS, CT, true>(args_by_value);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -633,11 +680,11 @@ struct TkStream { hipStream_t st; int dev; int parity; };
 TkStream g_tk_streams[PP_TK_STREAMS];
 int g_tk_n = 0;
 unsigned* g_tk_base[16] = {};
-int g_tk_mode = 1;     // mafed_gemm_set_variant(720) = static order everywhere, 721 = ticketed (default)
+int g_tk_mode = 2;     // mafed_gemm_set_variant: 720 = static order everywhere, 721 = ticketed everywhere, 722 = per call (MAFED_EPI_TICKETED; default)
 int g_tk_launches = 0; // test hook: launches that ran in ticketed order
 int g_num_cus = 0;
 }  // namespace
-void gemm_pp_set_ticket_mode(int on) { g_tk_mode = on ? 1 : 0; }
+void gemm_pp_set_ticket_mode(int mode) { g_tk_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 int gemm_pp_ticket_mode() { return g_tk_mode; }
 int gemm_pp_ticket_launches() { return g_tk_launches; }
 
@@ -682,28 +729,31 @@ static bool tk_acquire(hipStream_t st, unsigned** cur, unsigned** other, int* en
 }
 
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
-static int pp_launch_t(const PPArgs& a_in, double flops, hipStream_t st) {
+static int pp_launch_t(const PPArgs& a_in, double flops, hipStream_t st, bool ticketed) {
   constexpr int TM = MT * 16, TN = 8 * NT * 16;
   constexpr int LDS = NSTG * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES + 64;   // stages | epilogue strips | (trace) | ticket word
-  void (*kfn)(PPArgs);
-  if constexpr (A_KS && B_KS) kfn = gemm_pp_kernel_w<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
-  else kfn = gemm_pp_kernel<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
+  void (*kfn)(PPArgs) = gemm_pp_kernel<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;   // static tile order
+  void (*kfn_t)(PPArgs);                                                        // ticketed tile order
+  if constexpr (A_KS && B_KS) kfn_t = gemm_pp_kernel_w<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
+  else kfn_t = gemm_pp_kernel_t<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)kfn_t, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int ncu = gemm_pp_num_cus();
   const int grid = a_in.ntiles < ncu ? a_in.ntiles : ncu;
   PPArgs a = a_in;
+  a.grid = grid;
   a.tickets = a.tickets_clear = nullptr;
-  if (g_tk_mode && a.ntiles > grid && grid % 8 == 0) {
+  if (ticketed && a.ntiles > grid && grid % 8 == 0) {
     // more than one round: ticketed order.  Slot choice, parity flip and launch are one critical section, so that the alternation of
     // the two slots follows the stream's launch order whichever host thread launches.
     std::lock_guard<std::mutex> lk(g_tk_mu);
     int e = -1;
     if (tk_acquire(st, &a.tickets, &a.tickets_clear, &e)) {
-      launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(512), LDS, st, a);
+      launch(K_GEMM_PP, flops, kfn_t, dim3((unsigned)grid), dim3(512), LDS, st, a);
       if (hipPeekAtLastError() == hipSuccess) { g_tk_streams[e].parity ^= 1; ++g_tk_launches; }   // (a refused launch never ran: the slot stays the stream's current one)
       return MAFED_OK;
     }
@@ -767,13 +817,13 @@ int gemm_pp_pick(bool a_ks, bool b_ks, mafed_dtype c_dtype, int n, const int64_t
 }
 
 int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPProblem* probs, int n, const int64_t* Ms, const int64_t* Ns,
-                   const int64_t* Ks, hipStream_t st) {
+                   const int64_t* Ks, hipStream_t st, bool want_tickets) {
   if (n < 1 || n > PP_MAXP) { set_error("gemm_pp: 1..%d problems per launch", PP_MAXP); return MAFED_EINVAL; }
   int TM, TN;
   pp_tile_shape(cfg, TM, TN);
   PPArgs a;
   a.nprobs = n;
-  a.pad_ = 0;
+  a.grid = 0;   // (set by the launcher: the kernels read the grid size from the table, not from the dispatch packet)
   a.tickets = a.tickets_clear = nullptr;
   int tiles = 0;
   double flops = 0.0;
@@ -793,7 +843,9 @@ int gemm_pp_launch(int cfg, bool a_ks, bool b_ks, mafed_dtype c_dtype, const PPP
   // the 32 CUs of an XCD take 32 consecutive tile ids: GROUP_M row tiles x (32 / GROUP_M) column tiles form a compact patch
   a.group_m = min_tn >= 8 ? 4 : (min_tn >= 4 ? 8 : 16);
   if (cfg == PP_256x256) return gemm_z_launch(a_ks, b_ks, c_dtype, a, flops, st);
-#define PP_GO(MT, NT, NPH, NSTG, AKS, BKS, CT) return pp_launch_t<MT, NT, NPH, NSTG, AKS, BKS, CT>(a, flops, st)
+  // tile order of this launch: the caller's flag (MAFED_EPI_TICKETED, per call) unless the tuning hook forces one (720 static / 721 ticketed)
+  const bool ticketed = g_tk_mode == 2 ? want_tickets : g_tk_mode == 1;
+#define PP_GO(MT, NT, NPH, NSTG, AKS, BKS, CT) return pp_launch_t<MT, NT, NPH, NSTG, AKS, BKS, CT>(a, flops, st, ticketed)
   const bool f32 = c_dtype == MAFED_F32;
   if (a_ks && b_ks) {
     if (cfg == PP_128x256 && f32) PP_GO(8, 2, 2, 3, true, true, float);

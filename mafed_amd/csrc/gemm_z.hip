@@ -346,7 +346,9 @@ static int z_launch_t(const PPArgs& a, double flops, hipStream_t st) {
   }
   const int ncu = gemm_pp_num_cus();
   const int grid = a.ntiles < ncu ? a.ntiles : ncu;   // (static tile order: the ticketed order of gemm_pp.hip is not built into this kernel)
-  launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(256), LDS, st, a);
+  PPArgs a2 = a;
+  a2.grid = grid;
+  launch(K_GEMM_PP, flops, kfn, dim3((unsigned)grid), dim3(256), LDS, st, a2);
   return MAFED_OK;
 }
 

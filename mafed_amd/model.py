@@ -698,8 +698,13 @@ class VLPythiaForCausalLM(nn.Module):
         # 128 x 128 kernels' many small blocks lose 1.1 - 1.45x.  So this backward runs on those (Trainer sets the flag).
         # (per call: every GEMM this thread issues inside the block carries MAFED_EPI_NO_PERSISTENT; no process-wide switch is touched, a
         #  forced tuning variant or another thread's / model's launches are unaffected)
-        if getattr(self, "contended_backward", False) and self.flat_params.is_cuda:
-            with ops.no_persistent_gemm():
+        cb = getattr(self, "contended_backward", False)
+        if cb and self.flat_params.is_cuda:
+            # "ticketed": the persistent kernels stay, their blocks draw tiles from per-XCD queues (MAFED_EPI_TICKETED) -- a launch then
+            # tolerates the CUs the collective holds (1.2 - 1.3x instead of 1.7 - 1.9x with 8 - 32 CUs taken, tools/contention_bench.py);
+            # True / "128x128": every GEMM of this backward on the 128 x 128 kernels (round 3's choice)
+            ctx = ops.ticketed_gemm() if cb == "ticketed" else ops.no_persistent_gemm()
+            with ctx:
                 return self._engine_backward_impl(sv, dloss, dhidden, taps)
         return self._engine_backward_impl(sv, dloss, dhidden, taps)
 
@@ -756,7 +761,8 @@ class VLPythiaForCausalLM(nn.Module):
         # layer weight gradients, grouped: (dY, X, gradient) records wait here (the list keeps dY / X alive) until `flush_dw`
         # (beside collectives the weight gradients go back to one 128 x 128-kernel launch per product on the side streams, as in round 2:
         #  a grouped call would fall back to eight serial launches on the dX chain's stream)
-        group_dw = cd == torch.bfloat16 and int(getattr(self, "dw_group_layers", 0)) > 0 and not getattr(self, "contended_backward", False)
+        group_dw = (cd == torch.bfloat16 and int(getattr(self, "dw_group_layers", 0)) > 0
+                    and getattr(self, "contended_backward", False) in (False, None, "ticketed"))
         # First micro-batch of an accumulation window (Trainer sets ``grad_overwrite``): the grouped weight-gradient GEMMs WRITE the layers'
         # matrix gradients (beta = 0) instead of adding to a zeroed buffer -- the optimiser pass then does not zero-write those 1.2 GB
         # (FlatAdamW: ``skip_matrix_zero``) and the GEMM epilogues do not read them back.  ``_dw_stale`` = the last optimiser pass left the

@@ -13,7 +13,7 @@ from mafed_amd import _lib
 import contextlib
 import threading
 
-from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NO_PERSISTENT, EPI_NONE, EPI_QUICK_GELU, EPI_RES1_BF16, F32, check  # noqa: F401
+from mafed_amd._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NO_PERSISTENT, EPI_NONE, EPI_QUICK_GELU, EPI_RES1_BF16, EPI_TICKETED, F32, check  # noqa: F401
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -91,6 +91,19 @@ def no_persistent_gemm(on: bool = True):
     thread-local here: nothing process-wide is touched, other threads / models / forced tuning variants are unaffected."""
     prev = getattr(_tls, "no_pp", 0)
     _tls.no_pp = EPI_NO_PERSISTENT if on else prev
+    try:
+        yield
+    finally:
+        _tls.no_pp = prev
+
+
+@contextlib.contextmanager
+def ticketed_gemm(on: bool = True):
+    """Inside this block the calling thread's ``gemm`` / ``gemm_grouped`` calls carry MAFED_EPI_TICKETED: a launch that takes a persistent
+    kernel over several rounds draws its tiles from per-XCD queues (a backward that runs beside collectives or other long-resident
+    kernels).  Per call in the C-ABI, thread-local here, like :func:`no_persistent_gemm`."""
+    prev = getattr(_tls, "no_pp", 0)
+    _tls.no_pp = (prev | EPI_TICKETED) if on else prev
     try:
         yield
     finally:

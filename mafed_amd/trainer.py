@@ -57,7 +57,10 @@ class Trainer:
         # global-norm clip from per-range partials launched by the backward as each range becomes final (single process only: under
         # DDP the gradient hook belongs to the reducer; plugins that touch gradients outside the model's backward keep the one-pass norm)
         self.incremental_norm = bool(incremental_norm)
-        self.contention_aware = True   # DDP: 128 x 128 GEMM kernels while collectives share the chip (model._engine_backward)
+        # DDP, the backward that runs beside the bucket collectives (last micro-batch of a window): "ticketed" = persistent GEMM kernels in
+        # ticketed tile order, "128x128" = every GEMM of that backward on the 128 x 128 kernels (round 3), None = nothing special.
+        # (model._engine_backward; per call -- MAFED_EPI_TICKETED / MAFED_EPI_NO_PERSISTENT --, no process-wide switch)
+        self.contention_mode = "ticketed"
         # First micro-batch of a window WRITES the layers' weight-matrix gradients (beta = 0) and AdamW does not zero them: 1.2 GB less
         # written by the optimiser pass and 1.2 GB less read by the weight-gradient epilogues per step at 410M.  Single process, grouped
         # bf16 weight gradients only (`_overwrite_ok`); after a step the matrices' ``.grad`` holds the last gradient, not zeros.
@@ -93,6 +96,14 @@ class Trainer:
             loss = self.cl_method.compute_loss(self.model, loss, batch=batch)
         return loss, branch
 
+    @property
+    def contention_aware(self) -> bool:   # (round-3 name: True = the 128 x 128 kernels beside collectives)
+        return self.contention_mode == "128x128"
+
+    @contention_aware.setter
+    def contention_aware(self, v) -> None:
+        self.contention_mode = "128x128" if v else None
+
     def _overwrite_ok(self) -> bool:
         m = self.model
         return (self.overwrite_weight_grads and self.reducer is None and getattr(m, "compute_dtype", None) == torch.bfloat16
@@ -107,7 +118,7 @@ class Trainer:
             if window_end:
                 self.reducer.begin_window()
             # collectives run beside this backward: the model keeps its GEMMs off the one-block-per-CU persistent kernels meanwhile
-            self.model.contended_backward = bool(window_end and self.reducer.world > 1 and self.contention_aware)
+            self.model.contended_backward = self.contention_mode if (window_end and self.reducer.world > 1 and self.contention_mode) else False
         inc_norm = (window_end and self.reducer is None and self.grad_norm and self.grad_norm > 0 and self.incremental_norm
                     and getattr(self.cl_method, "grads_only_through_model", False) and hasattr(self.model, "grad_ready_hook")
                     and self.model.flat_grads.is_cuda)
@@ -139,7 +150,7 @@ class Trainer:
             self.cl_method.update_after_backward(model=self.model)  # on_before_optimizer_step
             if self.reducer is not None:
                 self.reducer.wait()
-                if self.reducer.world > 1 and self.contention_aware and torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
+                if self.reducer.world > 1 and self.contention_mode == "128x128" and torch.cuda.is_available() and hasattr(self.cl_method, "_prefetch_teacher"):
                     # the next step's teacher forward (persistent GEMMs) starts behind the last bucket's collective, not beside it
                     self.cl_method.backward_done_event = torch.cuda.current_stream().record_event()
             if self.grad_norm and self.grad_norm > 0:

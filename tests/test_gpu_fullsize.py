@@ -298,3 +298,36 @@ def test_contended_backward_keeps_off_the_persistent_kernels():
     fd.mem_dataloader = [dict(batch)]
     fd.replay(student)
     assert lib.mafed_gemm_pp_launches() - n2 > 80
+
+
+def test_contended_backward_ticketed_keeps_the_persistent_kernels_and_a_forced_variant():
+    """``contended_backward = "ticketed"`` (the data-parallel default of round 4): the backward stays on the persistent kernels, its
+    multi-round launches run in ticketed tile order (MAFED_EPI_TICKETED, per call), the forward does not; gradients equal the plain
+    backward's.  ADVICE r3: the choice is per call -- a variant the caller forced before (here 720 = static order everywhere, and the
+    tile-configuration variant) is what the hooks still say afterwards."""
+    from mafed_amd import _lib
+    lib = _lib.load()
+    cfg, student, fd = _setup(preset="410m")
+    batch = _batch(cfg)
+    loss_a, grads_a = _replay_grads(student, fd, batch)
+    t0, p0 = lib.mafed_gemm_get_variant(73), lib.mafed_gemm_pp_launches()
+    student.contended_backward = "ticketed"
+    loss_b, grads_b = _replay_grads(student, fd, batch)
+    n_tk, n_pp = lib.mafed_gemm_get_variant(73) - t0, lib.mafed_gemm_pp_launches() - p0
+    assert loss_a == loss_b
+    assert n_pp > 150 and 30 < n_tk < 60, (n_pp, n_tk)          # the multi-round launches of the backward (24 dX of fc2 + 12 grouped dW + head), none of the forward
+    den = float(grads_a.norm())
+    assert float((grads_a - grads_b).norm()) <= 3e-3 * den    # same kernels' arithmetic, another tile order (atomics noise only)
+    # a forced mode survives the contended backward (no process-wide switch is flipped and restored to a default)
+    lib.mafed_gemm_set_variant(720)
+    try:
+        t1 = lib.mafed_gemm_get_variant(73)
+        _replay_grads(student, fd, batch)
+        assert lib.mafed_gemm_get_variant(73) == t1, "720 = static order everywhere, whatever the call asks for"
+        assert lib.mafed_gemm_get_variant(72) == 720 and lib.mafed_gemm_get_variant(7) == 701
+        student.contended_backward = "128x128"
+        _replay_grads(student, fd, batch)
+        assert lib.mafed_gemm_get_variant(72) == 720 and lib.mafed_gemm_get_variant(7) == 701
+    finally:
+        lib.mafed_gemm_set_variant(722)
+        student.contended_backward = False

@@ -32,6 +32,25 @@ def test_dma_schedule_has_no_raw_or_war_hazard(c, nst, extra):
     assert P.check_schedule(c, nst=nst, extra_epilogue_ops=extra) == []
 
 
+@pytest.mark.parametrize("c", CFGS, ids=IDS)
+@pytest.mark.parametrize("nst,extra", [(9, 0), (18, 0), (9, 9), (16, 20)])
+def test_dma_schedule_with_the_ticket_atomic(c, nst, extra):
+    """Ticketed order: one more operation (the returning atomic) in the ticket wave's epilogue, one more tolerated by its first wait
+    behind the epilogue -- also when the epilogue issues exactly NST stores and nothing else."""
+    assert P.check_schedule(c, nst=nst, extra_epilogue_ops=extra, ticket=True) == []
+
+
+def test_checker_detects_the_relaxed_wait_without_its_atomic(monkeypatch):
+    """The +1 is only sound because the atomic is really in the queue: relax the wait in a launch whose epilogue does not carry it."""
+    c = P.Cfg("144x256", False, False, True)
+    real = P.waits_of
+    # (wave 2: its youngest piece in front of the epilogue feeds phase 0 of the next K-tile -- wave 7's feeds phase 1, which is why the
+    #  kernel's ticket wave has a whole interval of slack even without the atomic)
+    monkeypatch.setattr(P, "TICKET_WAVE", 2)
+    monkeypatch.setattr(P, "waits_of", lambda c, wave, post, nst: real(c, wave, post, nst, ticket=True))
+    assert P.check_schedule(c, nst=9, extra_epilogue_ops=0, ticket=False) != []
+
+
 def test_checker_detects_a_loosened_wait(monkeypatch):
     c = P.Cfg("144x256", False, False, True)
     monkeypatch.setattr(P, "waits_of", lambda c, wave, post, nst: {1: 6, 2: 5})

@@ -285,11 +285,16 @@ def piece_regions(c, wave, kind, i):
     return {("A", (pj * 8) // (c.MTP * 16))}
 
 
-def waits_of(c, wave, post, nst):
-    """vmcnt immediates after the issue of phase slot p (None = no wait)."""
+TICKET_WAVE = 7
+
+
+def waits_of(c, wave, post, nst, ticket=False):
+    """vmcnt immediates after the issue of phase slot p (None = no wait).  ``ticket``: the launch runs in ticketed order -- the ticket
+    wave's epilogue carries one returning atomic in front of its stores, and its first wait behind the epilogue tolerates it (round 4)."""
     if c.NPH == 3:
         n1 = 5 if (c.TM % 64 == 0 or wave < 2) else 4
-        return {1: min(63, n1 + nst) if post == 1 else n1, 2: 5}
+        relax = 1 if (ticket and wave == TICKET_WAVE and wave >= 2) else 0
+        return {1: min(63, n1 + nst + relax) if post == 1 else n1, 2: 5}
     return {0: min(63, 6 + nst) if post == 1 else 6}
 
 
@@ -300,7 +305,7 @@ def issue_of(c, p):
     return [(2, 1), (3, 0)][p]
 
 
-def check_schedule(c, nkt=6, ntiles=3, nst=9, extra_epilogue_ops=7):
+def check_schedule(c, nkt=6, ntiles=3, nst=9, extra_epilogue_ops=7, ticket=False):
     NPH, NSTG = c.NPH, c.NSTG
     # global stream K-tile index s = tile * nkt + kt; stage = s % NSTG
     issue_bi = {}     # (wave, s, kind, i) -> interval of issue
@@ -336,7 +341,7 @@ def check_schedule(c, nkt=6, ntiles=3, nst=9, extra_epilogue_ops=7):
             for kt in range(nkt):
                 s = t * nkt + kt
                 post = (kt + 1) if (t > 0 and kt < 2) else 0
-                w = waits_of(c, wave, post, nst)
+                w = waits_of(c, wave, post, nst, ticket) if ticket else waits_of(c, wave, post, nst)
                 for p in range(NPH):
                     f_bi = base + kt * NPH + p                    # this interval: cluster of phase p, reads of phase p + 1
                     regs = [("A", p)] + ([("B",)] if p == 0 else [])
@@ -348,8 +353,8 @@ def check_schedule(c, nkt=6, ntiles=3, nst=9, extra_epilogue_ops=7):
                     if p in w:
                         do_wait(w[p], f_bi)
             # epilogue: its loads are waited for inside it; at least nst stores stay queued
-            for _ in range(nst + extra_epilogue_ops):
-                queue.append(("st",))
+            for _ in range(nst + extra_epilogue_ops + (1 if (ticket and wave == TICKET_WAVE and c.NPH == 3) else 0)):
+                queue.append(("st",))   # (the ticket atomic counts like a store: an operation of the epilogue that is not a DMA)
             base += nkt * NPH
     errors = []
     total_s = ntiles * nkt

@@ -4,8 +4,8 @@ The ticket is drawn by an inline-asm returning atomic whose value lands in a VGP
 nothing about that latency (cdna_hip_programming.md 5.7: "an asm load's VGPR destination counts as written at ASMEND").  The kernel is
 correct only if the compiler leaves that register alone until the value has been parked in LDS.  This script compiles the file to ISA
 and checks, for every instantiation of gemm_pp_kernel:
-  * gemm_pp_kernel (asynchronous draw): every ticket atomic returns into v255, and NO other instruction of the kernel names v252 - v255
-    (the registers above the compiler's cap) except the park's `v_mov_b32 vN, v255` -- no copy, spill or re-use can exist;
+  * gemm_pp_kernel_t (asynchronous draw): every ticket atomic returns into v255, and NO other instruction of the kernel names v252 - v255
+    (the registers above the compiler's cap) except the park's `ds_write_b32 vN, v255` -- no copy, spill or re-use can exist;
   * gemm_pp_kernel_w (synchronous draw, the weight-gradient layout): every ticket atomic is followed by its own `s_waitcnt vmcnt(0)`;
   * no kernel has scratch (a spilled register puts a vmcnt(0) for its reload into the K loop).
 """
@@ -45,7 +45,7 @@ def audit(isa):
     rows = []
     fn, body = None, []
     for line in isa.split("\n"):
-        m = re.match(r"^(_ZN5mafed1\dgemm_pp_kernel\w+):", line)
+        m = re.match(r"^(_ZN5mafed1\dgemm_pp_kernel_[tw]\w+):", line)   # the ticketed instantiations (gemm_pp_kernel itself carries no ticket code)
         if m:
             fn, body = m.group(1), []
             continue
@@ -81,7 +81,7 @@ def audit_kernel(fn, body):
             continue
         if re.match(r"global_atomic_add\s+v255,", c):
             continue
-        if re.match(r"v_mov_b32(_e32)?\s+v\d+,\s*v255$", c) and 255 not in regs_named(c.split(",")[0]):
+        if re.match(r"ds_write_b32\s+v\d+,\s*v255$", c) and 255 not in regs_named(c.split(",")[0]):
             parks += 1
             continue
         hit = named.intersection(RESERVED)
@@ -96,7 +96,7 @@ def audit_kernel(fn, body):
         elif not re.match(r"global_atomic_add\s+v255,", c):
             problems.append(f"line {i}: ticket atomic `{c}` does not land in v255")
     if not sync and parks == 0:
-        problems.append("no park (v_mov_b32 vN, v255) found")
+        problems.append("no park (ds_write_b32 vN, v255) found")
     return {"kernel": fn, "reg": None if sync else 255, "atomics": len(atomics), "parks": parks, "sync": sync, "problems": problems}
 
 
