@@ -642,6 +642,7 @@ static int g_gemm_split = 0;  // 0 automatic, 1 never split K, n > 1 force n spl
 static int g_gemm_pp = 1;        // persistent ping-pong kernel (gemm_pp.hip): 700 = off, 701 = automatic (default), 710 + c = force configuration c
 static int g_gemm_pp_force = -1;
 static int g_gemm_pp_launches = 0;   // test hook: how many launches took the ping-pong kernel
+static int g_gemm_pp_fc2 = 0;        // tuning (730 off / 731 on): the fp32 + two-residual epilogue (4h -> h product) on the persistent kernel too
 extern "C" int mafed_gemm_pp_launches(void) { return g_gemm_pp_launches; }
 namespace mafed { extern int g_skinny_ns, g_skinny_wide; }
 extern "C" int mafed_gemm_get_variant(int which) {   // which: 0 = tile-configuration variant, 7 = persistent-kernel mode (700 / 701 / 710 + c)
@@ -651,7 +652,8 @@ extern "C" int mafed_gemm_get_variant(int which) {   // which: 0 = tile-configur
   return g_gemm_variant;
 }
 extern "C" int mafed_gemm_set_variant(int v) {
-  if (v >= 720 && v <= 722) { gemm_pp_set_ticket_mode(v - 720); return MAFED_OK; }   // persistent kernels: static / ticketed tile order / per call
+  if (v >= 720 && v <= 722) { gemm_pp_set_ticket_mode(v - 720); return MAFED_OK; }
+  if (v == 730 || v == 731) { g_gemm_pp_fc2 = v - 730; return MAFED_OK; }   // persistent kernels: static / ticketed tile order / per call
   if (v >= 700 && v < 800) { g_gemm_pp = v == 700 ? 0 : 1; g_gemm_pp_force = v >= 710 ? v - 710 : -1; return MAFED_OK; }
   if (v >= 600) { g_skinny_wide = v == 699 ? -1 : v - 600; return MAFED_OK; }
   if (v >= 500) { g_skinny_ns = v - 500; return MAFED_OK; }
@@ -815,7 +817,7 @@ static int gemm_impl(mafed_dtype in_dtype, int transA, int transB, int64_t M, in
       // fp32 C with both residual operands (the 4h -> h product): the register-direct epilogue moves 64-byte (fp32) and 32-byte (bf16
       // residual) row segments, twice the memory requests of the LDS-staged epilogue of the 128 x 128 kernel for the same bytes --
       // 82.5 us against 78.5 for the whole product, at any prefetch depth (3 / 8 / 12 items: 82.4 / 83.0 / 82.4 us)
-      if (pcfg != PP_NONE && g_gemm_pp_force < 0 && c_dtype == MAFED_F32 && epi.res1 && epi.res2) pcfg = PP_NONE;
+      if (pcfg != PP_NONE && g_gemm_pp_force < 0 && c_dtype == MAFED_F32 && epi.res1 && epi.res2 && !g_gemm_pp_fc2) pcfg = PP_NONE;
       if (pcfg != PP_NONE) {
         rc = gemm_pp_launch(pcfg, a_ks, b_ks, c_dtype, &pr, 1, &M, &N, &K, st, want_tickets);
         if (rc != MAFED_OK) return rc;

@@ -324,7 +324,7 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
     } else {
       // next tile of this block: static order id + G, ticketed order the id parked in LDS behind the previous epilogue (the prologue)
       int nid = d_id + G;
-      if (dyn) {   // (one asm statement = read + its own wait: a volatile LDS load makes hipcc drain vmcnt(0) -- the DMA ring -- around it)
+      if (TK && dyn) {   // (one asm statement = read + its own wait: a volatile LDS load makes hipcc drain vmcnt(0) -- the DMA ring -- around it)
         int v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(tk_lds_addr) : "memory");
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(v), r = t / (unsigned)tk_per;   // t-th draw of queue tk_q
@@ -623,12 +623,17 @@ __device__ __forceinline__ void gemm_pp_body(const PPArgs& args_by_value) {
     }
     trace_event(1);
     // (ticket for the tile after next: drawn inside the epilogue, parked in the first K-tile of the next tile)
-    if (!(MAFED_PP_ABL == 5 || MAFED_PP_ABL == 7) || !has_next) epilogue(tm, tn);
+    if (!(MAFED_PP_ABL == 5 || MAFED_PP_ABL == 7) || (TK ? !has_next : id + G >= ntiles)) epilogue(tm, tn);
     else if (TK && tk_wave) tk_issue();
     trace_event(2);
     first = false;
-    if (!has_next) break;
-    id = d_id;
+    if constexpr (TK) {
+      if (!has_next) break;
+      id = d_id;
+    } else {   // (the static kernel keeps round 3's own tile counter: nothing of the ticket bookkeeping is live across its K loop)
+      id += G;
+      if (id >= ntiles) break;
+    }
     // the DMA stream switched to this tile K-tiles ago: its coordinates are already decoded
     if (d_pi != pi) load_cq(d_pi);
     pi = d_pi; tm = d_tm; tn = d_tn;
@@ -731,7 +736,7 @@ static bool tk_acquire(hipStream_t st, unsigned** cur, unsigned** other, int* en
 template <int MT, int NT, int NPH, int NSTG, bool A_KS, bool B_KS, typename CT>
 static int pp_launch_t(const PPArgs& a_in, double flops, hipStream_t st, bool ticketed) {
   constexpr int TM = MT * 16, TN = 8 * NT * 16;
-  constexpr int LDS = NSTG * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES + 64;   // stages | epilogue strips | (trace) | ticket word
+  constexpr int LDS = NSTG * (TM + TN) * 128 + 2048 + PP_TRACE_BYTES + 64;   // stages | epilogue strips | (trace) | ticket word (ticketed kernels)
   void (*kfn)(PPArgs) = gemm_pp_kernel<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;   // static tile order
   void (*kfn_t)(PPArgs);                                                        // ticketed tile order
   if constexpr (A_KS && B_KS) kfn_t = gemm_pp_kernel_w<MT, NT, NPH, NSTG, A_KS, B_KS, CT>;

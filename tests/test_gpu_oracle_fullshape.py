@@ -1,7 +1,7 @@
 """The benched arithmetic at the benched shape, beside the ORACLE.
 
 VLPythia-410M, 256 image + 32 text tokens -- BASELINE.json configs[2]:
-  * bf16 product path exactly as `bench.py` runs it (persistent MFMA GEMM kernels in ticketed order, polynomial erf-GELU epilogues, the
+  * bf16 product path exactly as `bench.py` runs it (persistent MFMA GEMM kernels, polynomial erf-GELU epilogues, the
     row-sparse LM head through the replay buffer's label hint, frozen-teacher forward, fused distillation-gradient injection) at the
     full batch of 32 against ``oracle.mafed_replay_loss(autocast_bf16=True)`` -- what the reference's Lightning precision="bf16"
     computes: loss, the 23 per-layer language / vision MSEs and the global gradient norm within 2e-2;
@@ -85,7 +85,7 @@ def test_bf16_bench_arithmetic_vs_oracle_autocast_at_410m_full_batch():
     loss.backward()
     torch.cuda.synchronize()
     assert lib.mafed_gemm_pp_launches() - n_pp > 200, "the persistent GEMM kernels did not run"
-    assert lib.mafed_gemm_get_variant(73) - n_tk > 100, "no launch ran in ticketed order"
+    assert lib.mafed_gemm_get_variant(73) - n_tk == 0, "single process: the step runs the static tile order (tickets are per call, for the backward beside collectives)"
     assert student.last_label_overflow is not None and int(student.last_label_overflow) == 0
     gn = float(student.flat_grads.double().norm())
     mod = fd.last_modality_losses.float().cpu().numpy()          # [23, 2] (lang, vision)
