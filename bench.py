@@ -597,7 +597,7 @@ def main():
         g_alone, g_step = merged(prof_alone, GEMM_TAGS), merged(prof_step, GEMM_TAGS)
         if g_alone or g_step:
             traffic, tsrc = None, None
-            for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:  # HBM-side bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE)
                     with open(os.path.join(ROOT, "profiles", cand)) as fp:
                         traffic = json.load(fp)["hbm_MB_per_launch"] * 1e6
@@ -614,8 +614,8 @@ def main():
                     "mode": f"sum(2MNK) / sum(kernel execution time) over {N_PROF} steps with the side streams off (each kernel has the chip to "
                             "itself), start/stop events on each launch = rocprofv3 --kernel-trace durations; `frac_in_step` = the same over "
                             f"{N_PROF} steps of the timed configuration (kernels of several streams share the chip)",
-                    "records": "profiles/r03_kernel_profile_no_overlap.csv / r03_kernel_profile_timed.csv (this command with --dump-profile); "
-                               "rocprofv3 --kernel-trace --stats of the same command: profiles/r03_bench_kernel_stats.csv",
+                    "records": "profiles/r04_kernel_profile_no_overlap.csv / r04_kernel_profile_timed.csv (this command with --dump-profile); "
+                               "rocprofv3 --kernel-trace --stats of the same command: profiles/r04_bench_kernel_stats.csv",
                     "launches_per_step": round(gm["launches"] / N_PROF, 1), "avg_launch_us": round(gm["avg_us"], 2),
                     "avg_gflop_per_launch": round(gm["work"] / gm["launches"] / 1e9, 3)}
             if g_step and g_alone:
