@@ -176,6 +176,19 @@ int mafed_attn_decode(const void* qkv_prefix, int S0, const void* qkv_new, int c
                       int B, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                       const int64_t* attention_mask, int T, void* out, void* stream);
 
+/* The same step over a cache of ROTATED keys: qkv_prefix's k part has been rotated in place once behind the prefill
+ * (mafed_rotate_k_rows), rows < t of qkv_new by the steps that appended them; this call rotates row t's k (as written by the QKV
+ * GEMM), uses it and writes it back rotated.  A step then loads k and v only -- no rotary partner chunk, no cos / sin rows per key
+ * (two thirds of the on-load form's load instructions).  rot % 16 == 0, D in {64, 128, 256}.  Same result as mafed_attn_decode up to
+ * the rounding of the stored rotated keys (bf16 cache: one more bf16 rounding on the first `rot` dims of k). */
+int mafed_attn_decode_prerot(const void* qkv_prefix, int S0, void* qkv_new, int cap, int t, mafed_dtype dtype,
+                             int B, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                             const int64_t* attention_mask, int T, void* out, void* stream);
+/* k part of every row of a [B,S,H,3,D] qkv tensor rotated in place for its position (row index within the sample): turns a prefill's
+ * fused-QKV output into the pre-rotated cache of mafed_attn_decode_prerot.  rot % 16 == 0. */
+int mafed_rotate_k_rows(void* qkv, mafed_dtype dtype, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                        void* stream);
+
 /* ---- online EWC penalty (mafed/methods/ewc.py:105-127) -------------------------------------
  * The reference's compute_regularization over named_parameters(), on the flat fp32 buffers:
  *   fwd: out[0] = beta * out[0] + half_lambda * sum_i fisher[i] * (p[i] - p_old[i])^2     (half_lambda = 0.5 * reg_lambda;

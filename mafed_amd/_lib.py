@@ -30,6 +30,8 @@ SIGNATURES = {
     "mafed_gemm_get_variant": (_i, [_i]),
     "mafed_gemm_pp_launches": (_i, []),
     "mafed_attn_decode": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "mafed_attn_decode_prerot": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "mafed_rotate_k_rows": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mafed_ewc_workspace_bytes": (_z, [_l]),
     "mafed_ewc_penalty_fwd": (_i, [_p, _p, _p, _l, _f, _f, _p, _p, _z, _p]),
     "mafed_ewc_penalty_bwd": (_i, [_p, _p, _p, _l, _f, _p, _p, _p]),

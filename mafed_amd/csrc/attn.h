@@ -18,7 +18,10 @@ int attn_ref_bwd_launch(const void* qkv, const void* out, const void* dout, cons
 
 template <typename T>
 int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
-                       const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st);
+                       const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st, bool prerot = false);
+// k part of every row of a [rows / S samples, S, H, 3, D] qkv tensor rotated in place for its position (decode cache)
+template <typename T>
+int rotate_k_rows_launch(void* qkv, int64_t rows, int S, int H, int D, int rot, const float* rc, const float* rs, hipStream_t st);
 
 int attn_mfma_fwd_launch(const void* qkv, const AttnShape& sh, const float* rc, const float* rs, const int64_t* am, void* out, float* lse,
                          hipStream_t st);

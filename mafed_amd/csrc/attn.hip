@@ -117,17 +117,42 @@ extern "C" int mafed_attn_fwd_exact_bf16(const void* qkv, int B, int S, int H, i
   return MAFED_OK;
 }
 
-extern "C" int mafed_attn_decode(const void* qkv_prefix, int S0, const void* qkv_new, int cap, int t, mafed_dtype dtype, int B, int H, int D,
-                                 int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* out,
-                                 void* stream) {
+static int attn_decode_impl(const void* qkv_prefix, int S0, const void* qkv_new, int cap, int t, mafed_dtype dtype, int B, int H, int D,
+                            int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* out,
+                            void* stream, bool prerot) {
   MAFED_CHECK_ARG(qkv_prefix && qkv_new && out && attention_mask, "attn_decode: null pointer");
   MAFED_CHECK_ARG(B > 0 && H > 0 && D > 0 && D <= 256 && S0 > 0 && T >= 0 && T <= S0 && cap > 0 && t >= 0 && t < cap,
                   "attn_decode: bad shape B=%d H=%d D=%d S0=%d T=%d cap=%d t=%d", B, H, D, S0, T, cap, t);
   MAFED_CHECK_ARG(rot >= 0 && rot <= D && rot % 2 == 0 && (rot == 0 || (rot_cos && rot_sin)), "attn_decode: rotary arguments invalid");
   hipStream_t st = as_stream(stream);
-  int rc = dtype == MAFED_F32 ? attn_decode_launch<float>(qkv_prefix, S0, qkv_new, cap, t, B, H, D, rot, S0 - T, T, rot_cos, rot_sin, attention_mask, out, st)
-                              : attn_decode_launch<bf16_t>(qkv_prefix, S0, qkv_new, cap, t, B, H, D, rot, S0 - T, T, rot_cos, rot_sin, attention_mask, out, st);
+  int rc = dtype == MAFED_F32 ? attn_decode_launch<float>(qkv_prefix, S0, qkv_new, cap, t, B, H, D, rot, S0 - T, T, rot_cos, rot_sin, attention_mask, out, st, prerot)
+                              : attn_decode_launch<bf16_t>(qkv_prefix, S0, qkv_new, cap, t, B, H, D, rot, S0 - T, T, rot_cos, rot_sin, attention_mask, out, st, prerot);
   if (rc) return rc;
   MAFED_CHECK_LAUNCH("attn_decode");
+  return MAFED_OK;
+}
+
+extern "C" int mafed_attn_decode(const void* qkv_prefix, int S0, const void* qkv_new, int cap, int t, mafed_dtype dtype, int B, int H, int D,
+                                 int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* out,
+                                 void* stream) {
+  return attn_decode_impl(qkv_prefix, S0, qkv_new, cap, t, dtype, B, H, D, rot, rot_cos, rot_sin, attention_mask, T, out, stream, false);
+}
+
+extern "C" int mafed_attn_decode_prerot(const void* qkv_prefix, int S0, void* qkv_new, int cap, int t, mafed_dtype dtype, int B, int H, int D,
+                                        int rot, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, int T, void* out,
+                                        void* stream) {
+  MAFED_CHECK_ARG(rot % 16 == 0 && (D == 64 || D == 128 || D == 256), "attn_decode_prerot: needs rot %% 16 == 0 and a head size of 64 / 128 / 256");
+  return attn_decode_impl(qkv_prefix, S0, qkv_new, cap, t, dtype, B, H, D, rot, rot_cos, rot_sin, attention_mask, T, out, stream, true);
+}
+
+extern "C" int mafed_rotate_k_rows(void* qkv, mafed_dtype dtype, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
+                                   void* stream) {
+  MAFED_CHECK_ARG(qkv && B > 0 && S > 0 && H > 0 && D > 0 && rot >= 0 && rot <= D && rot % 16 == 0 && (rot == 0 || (rot_cos && rot_sin)),
+                  "rotate_k_rows: bad arguments");
+  hipStream_t st = as_stream(stream);
+  int rc = dtype == MAFED_F32 ? rotate_k_rows_launch<float>(qkv, (int64_t)B * S, S, H, D, rot, rot_cos, rot_sin, st)
+                              : rotate_k_rows_launch<bf16_t>(qkv, (int64_t)B * S, S, H, D, rot, rot_cos, rot_sin, st);
+  if (rc) return rc;
+  MAFED_CHECK_LAUNCH("rotate_k_rows");
   return MAFED_OK;
 }

@@ -304,6 +304,23 @@ __device__ __forceinline__ void load_row8<bf16_t>(const bf16_t* __restrict__ p, 
   v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
 
+template <typename T>
+__device__ __forceinline__ void store_row8(T* __restrict__ p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store_row8<float>(float* __restrict__ p, const float (&v)[8]) {
+  store4(p, make_float4(v[0], v[1], v[2], v[3]));
+  store4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+}
+template <>
+__device__ __forceinline__ void store_row8<bf16_t>(bf16_t* __restrict__ p, const float (&v)[8]) {
+  uint4 r;
+  r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  r.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  r.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+
 // chunk c (8 dims) of a q / k row, rotated for position pos (tf:111-151); rot % 16 == 0
 template <typename T>
 __device__ __forceinline__ void load_chunk_rot8(const T* __restrict__ row, int c, int rot, const float* __restrict__ rc, const float* __restrict__ rs,
@@ -332,13 +349,18 @@ __device__ __forceinline__ void unpack_bf16x8(const uint4& r, float (&v)[8]) {
 // those lanes with DPP/permute adds and every row group keeps an online-softmax state (m, l, acc[8]) that the block merges at the
 // end.  Replaces the thread-per-key / exp / V three-phase form (19 us at B = 32, S = 288: its 256 threads covered 289+ keys in two
 // dependent rounds, the second one with 33 busy lanes).
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restrict__ qkv_pre, int S0, const T* __restrict__ qkv_new, int cap, int t,
+// PREROT (round 4): the cache holds ROTATED keys -- the prefix was rotated in place once behind the prefill (rotate_k_rows_kernel), every
+// generated row by the step that appended it (this kernel rotates row t, uses it from LDS and writes it back for the later steps).  A step
+// then loads k and v only: the on-load form fetched the rotary partner chunk and 64 bytes of cos / sin per lane and row on top of the
+// 32 bytes of k | v -- most of the load instructions of a kernel that is bound by how many loads it keeps in flight.
+template <typename T, int D, bool PREROT = false>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restrict__ qkv_pre, int S0, T* __restrict__ qkv_new, int cap, int t,
                                                                 int H, int rot, int P, int Tm, const float* __restrict__ rc,
                                                                 const float* __restrict__ rs, const int64_t* __restrict__ am,
                                                                 T* __restrict__ out) {
   constexpr int chunks = D / 8, groups = 256 / chunks;
   __shared__ float q_s[D];
+  __shared__ float knew_s[D];
   __shared__ float red[groups][D];
   __shared__ float ml[groups][2];
   const int tid = threadIdx.x;
@@ -346,11 +368,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
   const int nk = S0 + t + 1;
   const int64_t rstride = (int64_t)H * 3 * D;
   const T* pre = qkv_pre + ((int64_t)b * S0 * H + h) * 3 * D;
-  const T* neu = qkv_new + ((int64_t)b * cap * H + h) * 3 * D;
+  T* neu = qkv_new + ((int64_t)b * cap * H + h) * 3 * D;
   const int c = tid % chunks, kg = tid / chunks;
   const float scale = rsqrtf((float)D);
   float qr[8];
-  constexpr int UNR = D == 64 ? 5 : 4;  // rows in flight per thread: 5 x 32 row groups cover S <= 320 keys in two steps
+  constexpr int UNR = D == 64 ? (PREROT ? 10 : 5) : (PREROT ? 8 : 4);  // rows in flight per thread: 5 x 32 row groups cover S <= 320 keys in two steps (pre-rotated cache: one)
   float m = -INFINITY, l = 0.f;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // Every load of a step is unconditional (clamped row, partner chunk and cos / sin rows fetched by every lane, the mask word too) and
@@ -363,8 +385,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
   const float sgn = first ? -1.f : 1.f;
   int j0 = kg;
   do {  // at least one step per thread (rows past nk are clamped loads with p = 0): the barrier below is reached by every thread
-    uint4 kraw[UNR], praw[UNR], vraw[UNR];
-    float4 cs0[UNR], cs1[UNR], sn0[UNR], sn1[UNR];
+    uint4 kraw[UNR], praw[PREROT ? 1 : UNR], vraw[UNR];
+    float4 cs0[PREROT ? 1 : UNR], cs1[PREROT ? 1 : UNR], sn0[PREROT ? 1 : UNR], sn1[PREROT ? 1 : UNR];
     int64_t amv[UNR];
     int jj[UNR];
 #pragma unroll
@@ -375,12 +397,14 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
       const T* row = jc < S0 ? pre + (int64_t)jc * rstride : neu + (int64_t)(jc - S0) * rstride;
       if constexpr (sizeof(T) == 2) {
         kraw[u] = *reinterpret_cast<const uint4*>(row + D + c * 8);
-        praw[u] = *reinterpret_cast<const uint4*>(row + D + cpart * 8);
+        if constexpr (!PREROT) praw[u] = *reinterpret_cast<const uint4*>(row + D + cpart * 8);
         vraw[u] = *reinterpret_cast<const uint4*>(row + 2 * D + c * 8);
       }
-      const float* cp = rc + (int64_t)jc * half + ccs;
-      const float* sp = rs + (int64_t)jc * half + ccs;
-      cs0[u] = load4(cp); cs1[u] = load4(cp + 4); sn0[u] = load4(sp); sn1[u] = load4(sp + 4);
+      if constexpr (!PREROT) {
+        const float* cp = rc + (int64_t)jc * half + ccs;
+        const float* sp = rs + (int64_t)jc * half + ccs;
+        cs0[u] = load4(cp); cs1[u] = load4(cp + 4); sn0[u] = load4(sp); sn1[u] = load4(sp + 4);
+      }
       const int ti = jc >= P && jc < S0 ? jc - P : 0;
       amv[u] = am[(int64_t)b * Tm + ti];
     }
@@ -392,8 +416,24 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
         load_chunk_rot8<T>(neu + (int64_t)t * rstride, tid, rot, rc, rs, S0 + t, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) q_s[tid * 8 + e] = v[e];
+        if constexpr (PREROT) {
+          // this step's own key row: rotated here (it arrives un-rotated from the QKV GEMM), used from LDS below, written back rotated
+          // for the steps to come (this block is the only reader and writer of the (b, h) slice of row t)
+          float kv[8];
+          load_chunk_rot8<T>(neu + (int64_t)t * rstride + D, tid, rot, rc, rs, S0 + t, kv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) knew_s[tid * 8 + e] = kv[e];
+        }
       }
       __syncthreads();
+      if constexpr (PREROT) {
+        if (tid < chunks) {
+          float kv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) kv[e] = knew_s[tid * 8 + e];
+          store_row8<T>(neu + (int64_t)t * rstride + D + tid * 8, kv);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) qr[e] = q_s[c * 8 + e] * scale;
     }
@@ -404,22 +444,28 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
       float x[8], y[8], vv[8];
       if constexpr (sizeof(T) == 2) {
         unpack_bf16x8(kraw[u], x);
-        unpack_bf16x8(praw[u], y);
+        if constexpr (!PREROT) unpack_bf16x8(praw[u], y);
         unpack_bf16x8(vraw[u], vv);
       } else {
         const int jc = j < nk ? j : nk - 1;
         const T* row = jc < S0 ? pre + (int64_t)jc * rstride : neu + (int64_t)(jc - S0) * rstride;
         load_row8<T>(row + D + c * 8, x);
-        load_row8<T>(row + D + cpart * 8, y);
+        if constexpr (!PREROT) load_row8<T>(row + D + cpart * 8, y);
         load_row8<T>(row + 2 * D + c * 8, vv);
       }
-      const float cs[8] = {cs0[u].x, cs0[u].y, cs0[u].z, cs0[u].w, cs1[u].x, cs1[u].y, cs1[u].z, cs1[u].w};
-      const float sn[8] = {sn0[u].x, sn0[u].y, sn0[u].z, sn0[u].w, sn1[u].x, sn1[u].y, sn1[u].z, sn1[u].w};
       float s = 0.f;
+      if constexpr (PREROT) {
+        const bool own = j == nk - 1;   // the row this step appended: its rotated key is in LDS (the copy in memory may still be the un-rotated one)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float kr = inrot ? x[e] * cs[e] + sgn * y[e] * sn[e] : x[e];
-        s = fmaf(qr[e], kr, s);
+        for (int e = 0; e < 8; ++e) s = fmaf(qr[e], own ? knew_s[c * 8 + e] : x[e], s);
+      } else {
+        const float cs[8] = {cs0[u].x, cs0[u].y, cs0[u].z, cs0[u].w, cs1[u].x, cs1[u].y, cs1[u].z, cs1[u].w};
+        const float sn[8] = {sn0[u].x, sn0[u].y, sn0[u].z, sn0[u].w, sn1[u].x, sn1[u].y, sn1[u].z, sn1[u].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float kr = inrot ? x[e] * cs[e] + sgn * y[e] * sn[e] : x[e];
+          s = fmaf(qr[e], kr, s);
+        }
       }
 #pragma unroll
       for (int o = 1; o < chunks; o <<= 1) s += __shfl_xor(s, o, 64);
@@ -456,17 +502,58 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
   }
 }
 
+// In place: k part of every row of a [B,S,H,3,D] qkv tensor rotated for its position (row index within the sample); rot % 16 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void rotate_k_rows_kernel(T* __restrict__ qkv, int64_t rows, int S, int H, int D, int rot, const float* __restrict__ rc,
+                                                            const float* __restrict__ rs) {
+  const int hc = rot >> 4;                       // 8-element chunks in half the rotary range; chunk pair (c, c + hc) is one work item
+  const int64_t items = rows * H * hc, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= items) return;
+  const int c = (int)(i % hc);
+  const int64_t rh = i / hc, row = rh / H;
+  const int h = (int)(rh - row * H), pos = (int)(row % S), half = rot >> 1;
+  T* kp = qkv + (row * H + h) * 3 * D + D;
+  float a[8], b[8];
+  load_row8<T>(kp + c * 8, a);
+  load_row8<T>(kp + (c + hc) * 8, b);
+  const float* cp = rc + (int64_t)pos * half + c * 8;
+  const float* sp = rs + (int64_t)pos * half + c * 8;
+  float lo[8], hi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { lo[e] = a[e] * cp[e] - b[e] * sp[e]; hi[e] = b[e] * cp[e] + a[e] * sp[e]; }
+  store_row8<T>(kp + c * 8, lo);
+  store_row8<T>(kp + (c + hc) * 8, hi);
+}
+
+template <typename T>
+int rotate_k_rows_launch(void* qkv, int64_t rows, int S, int H, int D, int rot, const float* rc, const float* rs, hipStream_t st) {
+  if (rot == 0) return MAFED_OK;
+  if (rot % 16 != 0) { set_error("rotate_k_rows: rot %% 16 != 0"); return MAFED_EINVAL; }
+  const int64_t items = rows * H * (rot >> 4);
+  rotate_k_rows_kernel<T><<<dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st>>>((T*)qkv, rows, S, H, D, rot, rc, rs);
+  return MAFED_OK;
+}
+template int rotate_k_rows_launch<float>(void*, int64_t, int, int, int, int, const float*, const float*, hipStream_t);
+template int rotate_k_rows_launch<bf16_t>(void*, int64_t, int, int, int, int, const float*, const float*, hipStream_t);
+
 template <typename T>
 int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
-                       const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st) {
+                       const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st, bool prerot) {
   if (rot % 16 == 0 && (D == 64 || D == 128 || D == 256)) {
-#define GO(DV) attn_decode_fused_kernel<T, DV><<<dim3(H, B), dim3(256), 0, st>>>((const T*)qkv_pre, S0, (const T*)qkv_new, cap, t, H, rot, P, Tm, rc, rs, am, (T*)out)
-    if (D == 64) GO(64);
-    else if (D == 128) GO(128);
-    else GO(256);
+#define GO(DV, PR) attn_decode_fused_kernel<T, DV, PR><<<dim3(H, B), dim3(256), 0, st>>>((const T*)qkv_pre, S0, (T*)const_cast<void*>(qkv_new), cap, t, H, rot, P, Tm, rc, rs, am, (T*)out)
+    if (prerot) {
+      if (D == 64) GO(64, true);
+      else if (D == 128) GO(128, true);
+      else GO(256, true);
+    } else {
+      if (D == 64) GO(64, false);
+      else if (D == 128) GO(128, false);
+      else GO(256, false);
+    }
 #undef GO
     return MAFED_OK;
   }
+  if (prerot) { set_error("attn_decode: the pre-rotated cache needs rot %% 16 == 0 and a head size of 64 / 128 / 256"); return MAFED_EINVAL; }
   const size_t lds = (size_t)4 * (D + S0 + t + 1) * sizeof(float);
   if (lds > 160 * 1024) { set_error("attn_decode: %d keys too many for this kernel", S0 + t + 1); return MAFED_EINVAL; }
   auto k = attn_decode_kernel<T>;
@@ -475,9 +562,9 @@ int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap
   return MAFED_OK;
 }
 template int attn_decode_launch<float>(const void*, int, const void*, int, int, int, int, int, int, int, int, const float*, const float*,
-                                       const int64_t*, void*, hipStream_t);
+                                       const int64_t*, void*, hipStream_t, bool);
 template int attn_decode_launch<bf16_t>(const void*, int, const void*, int, int, int, int, int, int, int, int, const float*, const float*,
-                                        const int64_t*, void*, hipStream_t);
+                                        const int64_t*, void*, hipStream_t, bool);
 
 template int attn_ref_fwd_launch<float>(const void*, const AttnShape&, const float*, const float*, const int64_t*, void*, float*, hipStream_t);
 template int attn_ref_fwd_launch<bf16_t>(const void*, const AttnShape&, const float*, const float*, const int64_t*, void*, float*, hipStream_t);

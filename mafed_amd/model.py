@@ -554,7 +554,7 @@ class VLPythiaForCausalLM(nn.Module):
             # the new token's q | k | v row goes straight into the cache (row t of the per-layer [B, cap, 3*H*D] tensor)
             ops.gemm(ln1, w(pre + "attention.query_key_value.weight"), False, True, bias=self._p(pre + "attention.query_key_value.bias"),
                      out=cache.new[i][:, t, :])
-            ao = ops.attn_decode(cache.prefix[i], S0, cache.new[i], t, B, H, D, rot, cos, sin, cache.attention_mask)
+            ao = ops.attn_decode(cache.prefix[i], S0, cache.new[i], t, B, H, D, rot, cos, sin, cache.attention_mask, prerot=cache.prerot)
             attn = ops.gemm(ao, w(pre + "attention.dense.weight"), False, True, bias=self._p(pre + "attention.dense.bias"), out_dtype=cd)
             a = ops.gemm(ln2, w(pre + "mlp.dense_h_to_4h.weight"), False, True, bias=self._p(pre + "mlp.dense_h_to_4h.bias"), epilogue=EPI_GELU)
             x = ops.gemm(a, w(pre + "mlp.dense_4h_to_h.weight"), False, True, bias=self._p(pre + "mlp.dense_4h_to_h.bias"),
@@ -961,10 +961,24 @@ class _DecodeCache:
     """K/V cache of a greedy decode: per layer the prefill's [B*S0, 3*H*D] fused-QKV output (kept as written -- no split, no
     transpose, k un-rotated) and a [B, cap, 3*H*D] tensor that receives one row per generated token."""
 
-    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor):
+    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor, prerotate: bool = True):
         self.prefix, self.B, self.S0, self.cap, self.attention_mask = prefix, B, S0, max(1, cap), attention_mask
-        n = 3 * model.config.num_attention_heads * model.config.head_dim
+        cfg = model.config
+        n = 3 * cfg.num_attention_heads * cfg.head_dim
         self.new = [torch.zeros((B, self.cap, n), dtype=prefix[0].dtype, device=prefix[0].device) for _ in prefix]
+        # Pre-rotated cache (round 4): once the prefill's attention has read the un-rotated keys, rotate them in place -- every decode step
+        # then loads k and v only (mafed_attn_decode_prerot).  Needs rot % 16 == 0 and an MFMA head size (every VLPythia preset).
+        self.prerot = bool(prerotate) and cfg.rotary_ndims % 16 == 0 and cfg.head_dim in (64, 128, 256)
+        self._model = model
+        if self.prerot:
+            self.rotate_prefix()
+
+    def rotate_prefix(self) -> None:
+        """Rotate the prefix keys in place (call once per prefill: the prefix must hold what the QKV GEMMs wrote)."""
+        cfg = self._model.config
+        cos, sin = self._model.rotary_tables(self.S0 + self.cap)
+        for p in self.prefix:
+            ops.rotate_k_rows_(p, self.B, self.S0, cfg.num_attention_heads, cfg.head_dim, cfg.rotary_ndims, cos, sin)
 
 
 class _GraphedDecode:
@@ -982,8 +996,8 @@ class _GraphedDecode:
         self.am = torch.ones((B, T), dtype=torch.int64, device=dev)
         self.first_logits = torch.zeros((B, cfg.vocab_size), dtype=cd if cd != torch.float32 else torch.float32, device=dev)
         self.tokens = torch.zeros((B, max_new), dtype=torch.int64, device=dev)
-        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am)
-        model.rotary_tables(S0 + self.cache.cap)  # built (host -> device copy) before the capture, not inside it
+        model.rotary_tables(S0 + max(1, max_new))  # built (host -> device copy) before the capture, not inside it
+        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am)   # (rotates the still-empty prefix once: harmless)
         eos, pad = eos_token_id, pad_token_id
 
         def body():
@@ -1011,6 +1025,8 @@ class _GraphedDecode:
     def run(self, feats, ids, am) -> torch.Tensor:
         m = self.model
         st = m._engine_forward(feats, ids, am, None, False, train=False, qkv_out=self.prefix)
+        if self.cache.prerot:
+            self.cache.rotate_prefix()   # this prefill's keys, rotated in place for the captured steps
         self.am.copy_(am)
         self.first_logits.copy_(st["logits"][:, -1, :])
         self.graph.replay()

@@ -299,16 +299,23 @@ def vit_assemble(patch_emb: torch.Tensor, class_embedding: torch.Tensor, positio
     return out
 
 
+def rotate_k_rows_(qkv: torch.Tensor, B: int, S: int, H: int, D: int, rot: int, cos, sin) -> None:
+    """k part of a [B*S, H*3*D] (or [B,S,...]) qkv tensor rotated in place for each row's position (mafed_rotate_k_rows)."""
+    assert qkv.is_contiguous() and qkv.numel() == B * S * H * 3 * D and cos.shape[0] >= S
+    check(_lib.load().mafed_rotate_k_rows(_ptr(qkv), _dt(qkv), B, S, H, D, rot, _ptr(cos), _ptr(sin), _stream()), "mafed_rotate_k_rows")
+
+
 def attn_decode(qkv_prefix: torch.Tensor, S0: int, qkv_new: torch.Tensor, t: int, B: int, H: int, D: int, rot: int, cos, sin,
-                attention_mask: torch.Tensor) -> torch.Tensor:
+                attention_mask: torch.Tensor, prerot: bool = False) -> torch.Tensor:
     """One decode step of attention: query = row t of ``qkv_new`` [B,cap,3*H*D], keys = the prefill's ``qkv_prefix``
     [B*S0, 3*H*D] followed by rows 0..t of ``qkv_new``.  -> [B, H*D]"""
     cap = qkv_new.shape[1]
     assert qkv_new.dim() == 3 and qkv_new.is_contiguous() and qkv_prefix.is_contiguous() and qkv_new.dtype == qkv_prefix.dtype
     assert cos.shape[0] >= S0 + t + 1
     out = torch.empty((B, H * D), dtype=qkv_new.dtype, device=qkv_new.device)
-    check(_lib.load().mafed_attn_decode(_ptr(qkv_prefix), S0, _ptr(qkv_new), cap, t, _dt(qkv_new), B, H, D, rot, _ptr(cos), _ptr(sin),
-                                        _ptr(attention_mask), attention_mask.shape[1], _ptr(out), _stream()), "mafed_attn_decode")
+    fn = _lib.load().mafed_attn_decode_prerot if prerot else _lib.load().mafed_attn_decode
+    check(fn(_ptr(qkv_prefix), S0, _ptr(qkv_new), cap, t, _dt(qkv_new), B, H, D, rot, _ptr(cos), _ptr(sin),
+             _ptr(attention_mask), attention_mask.shape[1], _ptr(out), _stream()), "mafed_attn_decode")
     return out
 
 

@@ -9,9 +9,9 @@ set -e
 OUT=gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 500 python3 bench.py --dump-profile $OUT 2> $OUT/bench_stderr.log | tail -1 > $OUT/bench_line.json
+if [ "$SKIP_BENCH" != "1" ]; then timeout -k 10 500 python3 bench.py --dump-profile $OUT 2> $OUT/bench_stderr.log | tail -1 > $OUT/bench_line.json; fi
 rm -rf gpurun_out/prof_kt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --no-ddp-forecast > /dev/null 2>&1
 ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
 kt=$(find gpurun_out/prof_kt -name "*kernel_trace.csv" | head -1)
 python3 - "$ks" "$kt" $OUT <<'PY'
@@ -20,7 +20,7 @@ from collections import defaultdict
 ks, kt, out = sys.argv[1:4]
 short = lambda n: re.sub(r"\(.*", "", n).replace("void mafed::", "").replace("mafed::", "")
 with open(ks) as f, open(out + "/bench_kernel_stats.csv", "w") as g:
-    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (1x MI355X)\n")
+    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --no-ddp-forecast   (1x MI355X)\n")
     r = csv.DictReader(f)
     g.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for row in r:
@@ -41,20 +41,21 @@ PY
 python3 tools/trace_timeline.py "$kt" 8 > $OUT/timeline.txt
 rm -rf gpurun_out/prof_kt
 # the same with every kernel alone on the chip (--no-overlap: one stream): what the per-kernel `*_no_overlap` figures of the line are checked against
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --no-overlap --no-pipeline-optimizer > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --no-ddp-forecast --no-overlap --no-pipeline-optimizer > /dev/null 2>&1
 ks=$(find gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1)
 python3 - "$ks" $OUT <<'PY'
 import csv, re, sys
 ks, out = sys.argv[1:3]
 short = lambda n: re.sub(r"\(.*", "", n).replace("void mafed::", "").replace("mafed::", "")
 with open(ks) as f, open(out + "/bench_no_overlap_kernel_stats.csv", "w") as g:
-    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --no-overlap --no-pipeline-optimizer   (1x MI355X; one stream)\n")
+    g.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-profile --no-secondary --no-image-leg --no-teacher-cache-leg --no-ddp-forecast --no-overlap --no-pipeline-optimizer   (1x MI355X; one stream)\n")
     g.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for row in csv.DictReader(f):
         g.write('"%s",%s,%s,%d,%s,%s,%s\n' % (short(row["Name"]), row["Calls"], row["TotalDurationNs"], float(row["AverageNs"]), row["Percentage"], row["MinNs"], row["MaxNs"]))
 PY
 rm -rf gpurun_out/prof_kt
 python3 tools/step_timeline.py > $OUT/step_timeline_inlib.txt 2>/dev/null || true
+if [ "$SKIP_PMC" = "1" ]; then cat $OUT/bench_line.json | cut -c1-300; exit 0; fi
 # HBM / fabric bytes per GEMM launch: per shape, isolated (tools/pmc_traffic.sh -> pmc_traffic.json with the private-L2 prediction)
 bash tools/pmc_traffic.sh > $OUT/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_shapes/pmc_traffic.json $OUT/pmc_traffic.json
