@@ -189,6 +189,31 @@ int mafed_attn_decode_prerot(const void* qkv_prefix, int S0, void* qkv_new, int 
 int mafed_rotate_k_rows(void* qkv, mafed_dtype dtype, int B, int S, int H, int D, int rot, const float* rot_cos, const float* rot_sin,
                         void* stream);
 
+/* ---- fused decode layer (mafed/model/vqa_cont_learner.py:260-277 -> HF greedy search over
+ * mafed/model/vl_pythia.py's GPT-NeoX stack, one row per sample and step) ----------------------------------------------
+ * A GPT-NeoX layer (parallel residual) of a decode step in three launches: mafed_decode_ln_qkv_fc1, mafed_attn_decode_prerot,
+ * mafed_decode_out.  bf16 weights [N, K] row-major, bf16 activations, fp32 residual stream x [M, h], M <= 64 rows.
+ * mafed_decode_supported: 1 if the shape is served (h % 256 == 0 with h / 256 in {1, 2, 3, 4, 8}, n1 % 32 == 0, ceil(M/16) * h/256 <= 16). */
+int mafed_decode_supported(int M, int h, int n1);
+/* qkv_out[m, 0:3h] = LN1(x[m]) . wqkv^T + bqkv   (row m at qkv_out + m * qkv_ld elements: the K/V cache row of this step)
+ * a_out[m, 0:n1]   = gelu(LN2(x[m]) . w1^T + b1) (erf form)
+ * Both LayerNorms (two-pass statistics in fp32, output rounded to bf16 like mafed_layernorm_fwd) are computed in the prologue. */
+int mafed_decode_ln_qkv_fc1(const float* x, int M, int h, float eps, const float* ln1_w, const float* ln1_b, const float* ln2_w,
+                            const float* ln2_b, const void* wqkv, const float* bqkv, void* qkv_out, int64_t qkv_ld, const void* w1,
+                            const float* b1, int n1, void* a_out, void* stream);
+/* out[m, 0:N] = LN(x[m]) . w^T (+ bias, may be NULL): the final LayerNorm folded into the LM head's product (the last two launches of a
+ * decode step as one).  bf16 w [N, h] and out (row stride ldo elements); N % 32 == 0; M, h as mafed_decode_supported(M, h, 32). */
+int mafed_decode_ln_linear(const float* x, int M, int h, float eps, const float* ln_w, const float* ln_b, const void* w, const float* bias,
+                           int64_t N, void* out, int64_t ldo, void* stream);
+/* x_out[m] = x[m] + bd + b2 + ao[m] . wd^T + act[m] . w2^T   (attention output projection and 4h -> h projection as one product over
+ * the concatenated K = h + n1; x_out may alias x).  The K reduction is split over blocks; partial tiles are added in slice order by the
+ * last block of a column group to arrive (no floating-point atomics: bit-identical from run to run).  workspace: at least
+ * mafed_decode_out_workspace_bytes(M, h) bytes, ZERO-FILLED once before the first call (it holds the arrival counters, which every
+ * launch leaves at zero again); one workspace per stream. */
+size_t mafed_decode_out_workspace_bytes(int M, int h);
+int mafed_decode_out(const float* x, float* x_out, int M, int h, int n1, const void* ao, const void* act, const void* wd,
+                     const float* bd, const void* w2, const float* b2, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- online EWC penalty (mafed/methods/ewc.py:105-127) -------------------------------------
  * The reference's compute_regularization over named_parameters(), on the flat fp32 buffers:
  *   fwd: out[0] = beta * out[0] + half_lambda * sum_i fisher[i] * (p[i] - p_old[i])^2     (half_lambda = 0.5 * reg_lambda;

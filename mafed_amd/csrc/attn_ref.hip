@@ -502,6 +502,119 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
   }
 }
 
+// Round 4, second form for the pre-rotated bf16 cache: every key row of the (b, h) slice is in flight at once (UNR x 256/chunks rows cover
+// nk), so the softmax needs no running state -- scores first, one block-wide max, then exp and the V sum; the row groups are merged with
+// register shuffles inside a wave and four LDS rows across the waves (the online form above merged 32 (m, l, acc) states with 32 dependent
+// expf per output element, and carried two expf per key row).  The prompt mask (Tm <= 256 text positions) is read once into LDS.
+template <int D, int UNR>
+__global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __restrict__ qkv_pre, int S0, bf16_t* __restrict__ qkv_new, int cap, int t,
+                                                               int H, int rot, int P, int Tm, const float* __restrict__ rc,
+                                                               const float* __restrict__ rs, const int64_t* __restrict__ am,
+                                                               bf16_t* __restrict__ out) {
+  constexpr int chunks = D / 8, groups = 256 / chunks;
+  __shared__ float red[4][D + 1];
+  __shared__ float wmax[4];
+  __shared__ unsigned char msk[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int nk = S0 + t + 1;
+  const int64_t rstride = (int64_t)H * 3 * D;
+  const bf16_t* pre = qkv_pre + ((int64_t)b * S0 * H + h) * 3 * D;
+  bf16_t* neu = qkv_new + ((int64_t)b * cap * H + h) * 3 * D;
+  const int c = tid % chunks, kg = tid / chunks;
+  // first in the queue (they come back first): the prompt mask word and this step's own q | k row -- every lane fetches chunk c of both
+  // and rotates it in registers (no wave waits on another one's round trip; all of it L2 hits after the first wave of the block)
+  const int64_t mword = am[(int64_t)b * Tm + (tid < Tm ? tid : Tm - 1)];   // (clamped, not predicated: a predicated load drains vmcnt(0) at the end of its region)
+  const int hc = rot >> 4, half = rot >> 1;
+  const bool inrot = c * 8 < rot, first = c < hc;
+  const int cpart = inrot ? (first ? c + hc : c - hc) : c;
+  const int ccs = inrot ? (first ? c : c - hc) * 8 : 0;
+  const bf16_t* qrow = neu + (int64_t)t * rstride;
+  const uint4 q0 = *reinterpret_cast<const uint4*>(qrow + c * 8), q1 = *reinterpret_cast<const uint4*>(qrow + cpart * 8);
+  const uint4 k0 = *reinterpret_cast<const uint4*>(qrow + D + c * 8), k1 = *reinterpret_cast<const uint4*>(qrow + D + cpart * 8);
+  const float* cp = rc + (int64_t)(S0 + t) * half + ccs;
+  const float* sp = rs + (int64_t)(S0 + t) * half + ccs;
+  const float4 cs0 = load4(cp), cs1 = load4(cp + 4), sn0 = load4(sp), sn1 = load4(sp + 4);
+  uint4 kraw[UNR], vraw[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {   // unconditional clamped loads: every key row of the slice in flight before anything waits
+    const int j = kg + u * groups;
+    const int jc = j < nk ? j : nk - 1;
+    const bf16_t* row = jc < S0 ? pre + (int64_t)jc * rstride : neu + (int64_t)(jc - S0) * rstride;
+    kraw[u] = *reinterpret_cast<const uint4*>(row + D + c * 8);
+    vraw[u] = *reinterpret_cast<const uint4*>(row + 2 * D + c * 8);
+  }
+  if (tid < Tm) msk[tid] = mword != 0;
+  const float scale = rsqrtf((float)D);
+  float qr[8], knew[8];
+  {
+    float a0[8], a1[8], b0[8], b1[8];
+    unpack_bf16x8(q0, a0); unpack_bf16x8(q1, a1); unpack_bf16x8(k0, b0); unpack_bf16x8(k1, b1);
+    const float cs[8] = {cs0.x, cs0.y, cs0.z, cs0.w, cs1.x, cs1.y, cs1.z, cs1.w};
+    const float sn[8] = {sn0.x, sn0.y, sn0.z, sn0.w, sn1.x, sn1.y, sn1.z, sn1.w};
+    const float sgn = first ? -1.f : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qr[e] = (inrot ? a0[e] * cs[e] + sgn * a1[e] * sn[e] : a0[e]) * scale;
+      knew[e] = inrot ? b0[e] * cs[e] + sgn * b1[e] * sn[e] : b0[e];
+    }
+  }
+  __syncthreads();   // mask bytes; also: every lane has read row t's un-rotated key before the write-back below
+  if (tid < chunks) store_row8<bf16_t>(neu + (int64_t)t * rstride + D + tid * 8, knew);   // rotated, for the steps to come (only this block touches the slice)
+  float sc[UNR];
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int j = kg + u * groups;
+    float x[8];
+    unpack_bf16x8(kraw[u], x);
+    const bool own = j == nk - 1;   // the row this step appended: its rotated key is in LDS (the copy in memory may still be the un-rotated one)
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(qr[e], own ? knew[e] : x[e], s);
+#pragma unroll
+    for (int o = 1; o < chunks; o <<= 1) s += __shfl_xor(s, o, 64);
+    const int ti = j >= P && j < S0 ? j - P : 0;
+    const bool ok = j < nk && (j < P || j >= S0 || msk[ti] != 0);
+    sc[u] = ok ? s : -INFINITY;
+    tmax = fmaxf(tmax, sc[u]);
+  }
+#pragma unroll
+  for (int o = chunks; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+  if (lane == 0) wmax[wave] = tmax;
+  __syncthreads();
+  float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  if (mx == -INFINITY) mx = 0.f;   // every key masked: p = 0 everywhere, the output is 0
+  float l = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    float vv[8];
+    unpack_bf16x8(vraw[u], vv);
+    const float p = __expf(sc[u] - mx);
+    l += p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
+  }
+#pragma unroll
+  for (int o = chunks; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (lane < chunks) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][c * 8 + e] = acc[e];
+    if (lane == 0) red[wave][D] = l;
+  }
+  __syncthreads();
+  if (tid < D) {
+    const float o = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    const float lt = (red[0][D] + red[1][D]) + (red[2][D] + red[3][D]);
+    out[(int64_t)b * H * D + (int64_t)h * D + tid] = f32_to_bf16(lt > 0.f ? o / lt : 0.f);
+  }
+}
+
 // In place: k part of every row of a [B,S,H,3,D] qkv tensor rotated for its position (row index within the sample); rot % 16 == 0.
 template <typename T>
 __global__ __launch_bounds__(256) void rotate_k_rows_kernel(T* __restrict__ qkv, int64_t rows, int S, int H, int D, int rot, const float* __restrict__ rc,
@@ -536,11 +649,26 @@ int rotate_k_rows_launch(void* qkv, int64_t rows, int S, int H, int D, int rot, 
 template int rotate_k_rows_launch<float>(void*, int64_t, int, int, int, int, const float*, const float*, hipStream_t);
 template int rotate_k_rows_launch<bf16_t>(void*, int64_t, int, int, int, int, const float*, const float*, hipStream_t);
 
+int g_attn_decode_flat = 1;   // mafed_gemm_set_variant(740 / 741)
+
 template <typename T>
 int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,
                        const float* rc, const float* rs, const int64_t* am, void* out, hipStream_t st, bool prerot) {
   if (rot % 16 == 0 && (D == 64 || D == 128 || D == 256)) {
 #define GO(DV, PR) attn_decode_fused_kernel<T, DV, PR><<<dim3(H, B), dim3(256), 0, st>>>((const T*)qkv_pre, S0, (T*)const_cast<void*>(qkv_new), cap, t, H, rot, P, Tm, rc, rs, am, (T*)out)
+    if constexpr (sizeof(T) == 2) {
+      // every key row in flight at once when the slice fits (see attn_decode_flat_kernel); g_attn_decode_flat = 0 keeps the online form (A/B)
+      if (prerot && g_attn_decode_flat && Tm <= 256 && (D == 64 || D == 128)) {
+        const int nk = S0 + t + 1, need = (nk + (256 / (D / 8)) - 1) / (256 / (D / 8));
+#define GOF(DV, UV) attn_decode_flat_kernel<DV, UV><<<dim3(H, B), dim3(256), 0, st>>>((const bf16_t*)qkv_pre, S0, (bf16_t*)const_cast<void*>(qkv_new), cap, t, H, rot, P, Tm, rc, rs, am, (bf16_t*)out)
+        if (D == 64 && need <= 10) { GOF(64, 10); return MAFED_OK; }
+        if (D == 64 && need <= 16) { GOF(64, 16); return MAFED_OK; }
+        if (D == 64 && need <= 24) { GOF(64, 24); return MAFED_OK; }
+        if (D == 128 && need <= 12) { GOF(128, 12); return MAFED_OK; }
+        if (D == 128 && need <= 24) { GOF(128, 24); return MAFED_OK; }
+#undef GOF
+      }
+    }
     if (prerot) {
       if (D == 64) GO(64, true);
       else if (D == 128) GO(128, true);

@@ -644,7 +644,7 @@ static int g_gemm_pp_force = -1;
 static int g_gemm_pp_launches = 0;   // test hook: how many launches took the ping-pong kernel
 static int g_gemm_pp_fc2 = 0;        // tuning (730 off / 731 on): the fp32 + two-residual epilogue (4h -> h product) on the persistent kernel too
 extern "C" int mafed_gemm_pp_launches(void) { return g_gemm_pp_launches; }
-namespace mafed { extern int g_skinny_ns, g_skinny_wide; }
+namespace mafed { extern int g_skinny_ns, g_skinny_wide, g_attn_decode_flat, g_decode_lds; }
 extern "C" int mafed_gemm_get_variant(int which) {   // which: 0 = tile-configuration variant, 7 = persistent-kernel mode (700 / 701 / 710 + c)
   if (which == 7) return g_gemm_pp_force >= 0 ? 710 + g_gemm_pp_force : (g_gemm_pp ? 701 : 700);
   if (which == 72) return 720 + gemm_pp_ticket_mode();
@@ -653,7 +653,9 @@ extern "C" int mafed_gemm_get_variant(int which) {   // which: 0 = tile-configur
 }
 extern "C" int mafed_gemm_set_variant(int v) {
   if (v >= 720 && v <= 722) { gemm_pp_set_ticket_mode(v - 720); return MAFED_OK; }
-  if (v == 730 || v == 731) { g_gemm_pp_fc2 = v - 730; return MAFED_OK; }   // persistent kernels: static / ticketed tile order / per call
+  if (v == 730 || v == 731) { g_gemm_pp_fc2 = v - 730; return MAFED_OK; }
+  if (v == 760 || v == 761) { g_decode_lds = v - 760; return MAFED_OK; }   // decode layer kernels: register-direct / LDS-staged loads
+  if (v == 740 || v == 741) { g_attn_decode_flat = v - 740; return MAFED_OK; }   // decode attention: online / all-rows-in-flight form   // persistent kernels: static / ticketed tile order / per call
   if (v >= 700 && v < 800) { g_gemm_pp = v == 700 ? 0 : 1; g_gemm_pp_force = v >= 710 ? v - 710 : -1; return MAFED_OK; }
   if (v >= 600) { g_skinny_wide = v == 699 ? -1 : v - 600; return MAFED_OK; }
   if (v >= 500) { g_skinny_ns = v - 500; return MAFED_OK; }

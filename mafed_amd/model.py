@@ -520,8 +520,8 @@ class VLPythiaForCausalLM(nn.Module):
             gen_all = gd.run(feats, ids, am)
             new_tokens = list(gen_all.unbind(1))
         else:
-            st = self._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
-            cache = _DecodeCache(self, [l["qkv"] for l in st["layers"]], B, st["S"], max_new_tokens, am)
+            st = self._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True, last_only=True)
+            cache = _DecodeCache(self, [l["qkv"] for l in st["layers"]], B, st["S"], max_new_tokens, am, fused=getattr(self, "fused_decode", True))
             nxt = pick(st["logits"][:, -1, :])
             for t in range(max_new_tokens - 1):
                 nxt = pick(self._engine_decode_step(nxt, t, cache))
@@ -546,6 +546,24 @@ class VLPythiaForCausalLM(nn.Module):
         cos, sin = self.rotary_tables(S0 + cache.cap)
         w = self._w
         x = self._p("gpt_neox.embed_in.weight").index_select(0, tokens)  # fp32 residual stream row
+        if cache.fused:
+            # three launches per layer (csrc/decode.hip): [LN1 | LN2] + QKV + fc1/GELU, attention over the pre-rotated cache, and
+            # dense + fc2 + both residuals as one product over the concatenated K
+            for i in range(L):
+                pre = f"gpt_neox.layers.{i}."
+                a = ops.decode_ln_qkv_fc1(x, self._p(pre + "input_layernorm.weight"), self._p(pre + "input_layernorm.bias"),
+                                          self._p(pre + "post_attention_layernorm.weight"), self._p(pre + "post_attention_layernorm.bias"),
+                                          cfg.layer_norm_eps, w(pre + "attention.query_key_value.weight"),
+                                          self._p(pre + "attention.query_key_value.bias"), cache.new[i][:, t, :],
+                                          w(pre + "mlp.dense_h_to_4h.weight"), self._p(pre + "mlp.dense_h_to_4h.bias"))
+                ao = ops.attn_decode(cache.prefix[i], S0, cache.new[i], t, B, H, D, rot, cos, sin, cache.attention_mask, prerot=True)
+                x = ops.decode_out(x, ao, a, w(pre + "attention.dense.weight"), self._p(pre + "attention.dense.bias"),
+                                   w(pre + "mlp.dense_4h_to_h.weight"), self._p(pre + "mlp.dense_4h_to_h.bias"), cache.workspace, out=x)
+            # (final LayerNorm folded into the head's launch -- ops.decode_ln_linear -- measured slower at V = 50k: 66 us against 48 for
+            #  the two launches, whose skinny kernel reads a bf16 row block per 16 vocabulary columns instead of an fp32 one per 128)
+            lnf, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                             None, None, cfg.layer_norm_eps, cd, save_stats=False)
+            return ops.gemm(lnf, w("embed_out.weight"), False, True)
         for i in range(L):
             pre = f"gpt_neox.layers.{i}."
             ln1, ln2, _, _ = ops.layernorm_fwd(x, self._p(pre + "input_layernorm.weight"), self._p(pre + "input_layernorm.bias"),
@@ -565,7 +583,8 @@ class VLPythiaForCausalLM(nn.Module):
 
     # ---- engine ------------------------------------------------------------------------------------------------------
     def _engine_forward(self, feats, input_ids, attention_mask, labels, want_hidden, train, n_hidden: Optional[int] = None,
-                        keep_qkv: bool = False, qkv_out: Optional[Sequence[torch.Tensor]] = None, label_rows_hint: Optional[int] = None):
+                        keep_qkv: bool = False, qkv_out: Optional[Sequence[torch.Tensor]] = None, label_rows_hint: Optional[int] = None,
+                        last_only: bool = False):
         if not self.flat_params.is_cuda:
             raise RuntimeError("mafed_amd runs on the GPU only (no CPU fallback); move the model with .cuda()")
         pe, main_st = self._param_events, torch.cuda.current_stream()
@@ -634,6 +653,13 @@ class VLPythiaForCausalLM(nn.Module):
             main_st.wait_event(pe["head"])
             self._param_events = None
         if n_hidden is not None:
+            return sv
+        if last_only:
+            # a decode prefill only needs the last position's logits: final LN + head on B rows instead of B * T (-> logits [B, 1, V])
+            xl = x.view(B, S, h)[:, -1, :].contiguous()
+            lnl, _, _, _ = ops.layernorm_fwd(xl, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                             None, None, cfg.layer_norm_eps, cd, save_stats=False)
+            sv["logits"] = ops.gemm(lnl, w("embed_out.weight"), False, True).view(B, 1, cfg.vocab_size)
             return sv
         # final LN (fp32 hidden state L only when asked for) + LM head on the T text positions (vl_pythia.py:89,310)
         xt = x.view(B, S, h)[:, P:, :].reshape(B * T, h)
@@ -961,7 +987,7 @@ class _DecodeCache:
     """K/V cache of a greedy decode: per layer the prefill's [B*S0, 3*H*D] fused-QKV output (kept as written -- no split, no
     transpose, k un-rotated) and a [B, cap, 3*H*D] tensor that receives one row per generated token."""
 
-    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor, prerotate: bool = True):
+    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor, prerotate: bool = True, fused: bool = True):
         self.prefix, self.B, self.S0, self.cap, self.attention_mask = prefix, B, S0, max(1, cap), attention_mask
         cfg = model.config
         n = 3 * cfg.num_attention_heads * cfg.head_dim
@@ -970,6 +996,9 @@ class _DecodeCache:
         # then loads k and v only (mafed_attn_decode_prerot).  Needs rot % 16 == 0 and an MFMA head size (every VLPythia preset).
         self.prerot = bool(prerotate) and cfg.rotary_ndims % 16 == 0 and cfg.head_dim in (64, 128, 256)
         self._model = model
+        # fused decode layer (csrc/decode.hip): bf16 mode over the pre-rotated cache, shapes per mafed_decode_supported
+        self.fused = bool(fused) and self.prerot and prefix[0].dtype == torch.bfloat16 and ops.decode_supported(B, cfg.hidden_size, cfg.intermediate_size)
+        self.workspace = ops.decode_out_workspace(B, cfg.hidden_size, prefix[0].device) if self.fused else None
         if self.prerot:
             self.rotate_prefix()
 
@@ -997,7 +1026,7 @@ class _GraphedDecode:
         self.first_logits = torch.zeros((B, cfg.vocab_size), dtype=cd if cd != torch.float32 else torch.float32, device=dev)
         self.tokens = torch.zeros((B, max_new), dtype=torch.int64, device=dev)
         model.rotary_tables(S0 + max(1, max_new))  # built (host -> device copy) before the capture, not inside it
-        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am)   # (rotates the still-empty prefix once: harmless)
+        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am, fused=getattr(model, "fused_decode", True))   # (rotates the still-empty prefix once: harmless)
         eos, pad = eos_token_id, pad_token_id
 
         def body():
@@ -1024,7 +1053,7 @@ class _GraphedDecode:
 
     def run(self, feats, ids, am) -> torch.Tensor:
         m = self.model
-        st = m._engine_forward(feats, ids, am, None, False, train=False, qkv_out=self.prefix)
+        st = m._engine_forward(feats, ids, am, None, False, train=False, qkv_out=self.prefix, last_only=True)
         if self.cache.prerot:
             self.cache.rotate_prefix()   # this prefill's keys, rotated in place for the captured steps
         self.am.copy_(am)

@@ -319,6 +319,63 @@ def attn_decode(qkv_prefix: torch.Tensor, S0: int, qkv_new: torch.Tensor, t: int
     return out
 
 
+def decode_supported(M: int, h: int, n1: int) -> bool:
+    """Shapes served by the fused decode layer kernels (``decode_ln_qkv_fc1`` / ``decode_out``)."""
+    return bool(_lib.load().mafed_decode_supported(int(M), int(h), int(n1)))
+
+
+def decode_ln_qkv_fc1(x: torch.Tensor, ln1_w, ln1_b, ln2_w, ln2_b, eps: float, wqkv: torch.Tensor, bqkv: torch.Tensor,
+                      qkv_row: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, a_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode step, first launch of a layer: ``qkv_row[m] = LN1(x[m]) @ wqkv^T + bqkv`` (a strided [M, 3h] view: the cache row of this
+    step) and ``a = gelu(LN2(x[m]) @ w1^T + b1)`` -> a [M, n1] bf16.  x fp32 [M, h]; weights bf16 [N, h]."""
+    M, h = x.shape
+    n1 = w1.shape[0]
+    assert x.dtype == torch.float32 and x.is_contiguous() and wqkv.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
+    assert wqkv.shape == (3 * h, h) and w1.shape[1] == h and wqkv.is_contiguous() and w1.is_contiguous()
+    assert qkv_row.shape == (M, 3 * h) and qkv_row.dtype == torch.bfloat16 and qkv_row.stride(1) == 1
+    if a_out is None:
+        a_out = torch.empty((M, n1), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().mafed_decode_ln_qkv_fc1(_ptr(x), M, h, float(eps), _ptr(ln1_w), _ptr(ln1_b), _ptr(ln2_w), _ptr(ln2_b), _ptr(wqkv),
+                                              _ptr(bqkv), _ptr(qkv_row), qkv_row.stride(0), _ptr(w1), _ptr(b1), n1, _ptr(a_out), _stream()),
+          "mafed_decode_ln_qkv_fc1")
+    return a_out
+
+
+def decode_ln_linear(x: torch.Tensor, ln_w, ln_b, eps: float, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``LN(x) @ w^T (+ bias)`` for a decode step's M <= 64 rows: final LayerNorm + LM head as one launch.  x fp32 [M, h], w bf16 [N, h]
+    -> bf16 [M, N]."""
+    M, h = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[1] == h
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    check(_lib.load().mafed_decode_ln_linear(_ptr(x), M, h, float(eps), _ptr(ln_w), _ptr(ln_b), _ptr(w), _ptr(bias), N, _ptr(out), out.stride(0),
+                                             _stream()), "mafed_decode_ln_linear")
+    return out
+
+
+def decode_out_workspace(M: int, h: int, device) -> torch.Tensor:
+    """Zero-filled workspace of ``decode_out`` (partial tiles + arrival counters; one per stream, re-usable across calls)."""
+    return torch.zeros(int(_lib.load().mafed_decode_out_workspace_bytes(int(M), int(h))), dtype=torch.uint8, device=device)
+
+
+def decode_out(x: torch.Tensor, ao: torch.Tensor, act: torch.Tensor, wd: torch.Tensor, bd: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+               workspace: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode step, last launch of a layer: ``x + bd + b2 + ao @ wd^T + act @ w2^T`` -> fp32 [M, h] (``out`` may be ``x``)."""
+    M, h = x.shape
+    n1 = act.shape[1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and ao.shape == (M, h) and ao.is_contiguous() and act.is_contiguous()
+    assert ao.dtype == torch.bfloat16 and act.dtype == torch.bfloat16 and wd.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+    assert wd.shape == (h, h) and w2.shape == (h, n1) and wd.is_contiguous() and w2.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().mafed_decode_out(_ptr(x), _ptr(out), M, h, n1, _ptr(ao), _ptr(act), _ptr(wd), _ptr(bd), _ptr(w2), _ptr(b2),
+                                       _ptr(workspace), workspace.numel(), _stream()), "mafed_decode_out")
+    return out
+
+
 def embed_concat_fwd(image: torch.Tensor, embed_in: torch.Tensor, input_ids: torch.Tensor, B: int, P: int, T: int) -> torch.Tensor:
     V, h = embed_in.shape
     h0 = torch.empty((B * (P + T), h), dtype=torch.float32, device=embed_in.device)

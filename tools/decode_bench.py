@@ -32,6 +32,11 @@ def run(use_cache, reps=5, use_graph=False):
 
 
 t_u, o_u = run(False)
+model.fused_decode = False
+t_e6, _ = run(True)
+t_c6, o_c6 = run(True, use_graph=True)
+model._decode_graphs = {}
+model.fused_decode = True
 t_e, o_e = run(True)
 t_c, o_c = run(True, use_graph=True)
 same = float((o_u == o_c).float().mean())
@@ -40,20 +45,46 @@ n_params = sum(p.numel() for p in model.parameters())
 wbytes = 2.0 * (n_params - cfg.vocab_size * cfg.hidden_size)  # bf16 weights streamed per decode step (all but embed_in)
 print(f"{model_name}: generate B={B} {P}+{T} tokens, {NEW} new: recompute {t_u * 1e3:.1f} ms ({B / t_u:.0f} ex/s), "
       f"KV-cached eager {t_e * 1e3:.1f} ms, KV-cached + hipGraph {t_c * 1e3:.1f} ms ({B / t_c:.0f} ex/s), speed-up {t_u / t_c:.2f}x, "
-      f"tokens equal {same:.3f}")
-# decode-step roofline: the (NEW - 1) cached steps stream the weights once each
-st = model._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
+      f"tokens equal {same:.3f}; six launches per layer: eager {t_e6 * 1e3:.1f} ms, hipGraph {t_c6 * 1e3:.1f} ms, tokens equal to the fused path {float((o_c6 == o_c).float().mean()):.3f}")
+# decode-step roofline: the (NEW - 1) cached steps stream the weights once each and every layer's K/V slice once
 from mafed_amd.model import _DecodeCache
-cache = _DecodeCache(model, [l["qkv"] for l in st["layers"]], B, st["S"], NEW, am)
-tok = ids[:, -1].contiguous()
-for t in range(3):
-    model._engine_decode_step(tok, t, cache)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for t in range(NEW - 1):
-    model._engine_decode_step(tok, t, cache)
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / (NEW - 1)
-print(f"decode step: {ms:.3f} ms; weights {wbytes / 1e9:.2f} GB per step -> {wbytes / ms / 1e9:.2f} TB/s ({wbytes / ms / 1e9 / 8.0 * 100:.1f} % of 8 TB/s)")
+kv_bytes = 0.0
+
+
+def step_ms(fused: bool):
+    """One cached step, timed inside a hipGraph replay of NEW - 1 steps (eager launches of 75 - 150 small kernels are host-bound)."""
+    global kv_bytes
+    st = model._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
+    cache = _DecodeCache(model, [l["qkv"] for l in st["layers"]], B, st["S"], NEW, am, fused=fused)
+    kv_bytes = cfg.num_hidden_layers * B * (st["S"] + NEW / 2) * 2 * cfg.hidden_size * 2.0
+    tok = ids[:, -1].contiguous()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for t in range(NEW - 1):
+            model._engine_decode_step(tok, t, cache)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for t in range(NEW - 1):
+            out = model._engine_decode_step(tok, t, cache)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(5):
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / (NEW - 1))
+    return best, cache.fused
+
+
+for fused in (True, False):
+    model.fused_decode = fused
+    ms, was_fused = step_ms(fused)
+    tot = wbytes + kv_bytes
+    print(f"decode step ({'three launches per layer' if was_fused else 'six launches per layer'}): {ms:.3f} ms; weights {wbytes / 1e9:.2f} GB + K/V {kv_bytes / 1e9:.2f} GB "
+          f"per step -> {tot / ms / 1e9:.2f} TB/s ({tot / ms / 1e9 / 8.0 * 100:.1f} % of 8 TB/s; weights alone {wbytes / ms / 1e9 / 8.0 * 100:.1f} %)")
+model.fused_decode = True
