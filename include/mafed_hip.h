@@ -335,6 +335,11 @@ int mafed_optim_advance_guarded(int64_t* state_dev, double base_lr, int64_t warm
 /* sumsq16[k] += the squares of part of x (k = 0..15, their total += sum x^2): the unfused form of mafed_gemm_problem.sumsq, and the way
  * to put any fp32 range into the same 16 slots.  x 16-byte aligned. */
 int mafed_sumsq_accumulate(const float* x, int64_t n, float* sumsq16, void* stream);
+/* 1 if mafed_gemm_grouped would run these n products (dense operands) as ONE persistent launch that fills mafed_gemm_problem.sumsq from its
+ * epilogue; 0 if the squares would cost a pass over C behind the product(s) (shapes the 256 x 256-tile kernel takes, groups that do not
+ * fill the chip) -- a caller that has a cheaper way to the same norm (mafed_gradnorm_partial over a contiguous range) then skips sumsq. */
+int mafed_gemm_grouped_fuses_sumsq(mafed_dtype in_dtype, int transA, int transB, mafed_dtype c_dtype, const int64_t* M, const int64_t* N,
+                                   const int64_t* K, int n);
 
 /* mafed_gradnorm_finish followed by mafed_optim_advance as ONE launch (both are single-thread tails on the optimiser step's critical
  * path); norm_log (or NULL) additionally receives the norm -- a slot the caller owns, e.g. for the step's log record, so that no

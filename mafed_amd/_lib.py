@@ -32,6 +32,7 @@ SIGNATURES = {
     "mafed_attn_decode": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "mafed_attn_decode_prerot": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "mafed_rotate_k_rows": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "mafed_gemm_grouped_fuses_sumsq": (_i, [_i, _i, _i, _i, _p, _p, _p, _i]),
     "mafed_decode_supported": (_i, [_i, _i, _i]),
     "mafed_decode_ln_qkv_fc1": (_i, [_p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p]),
     "mafed_decode_ln_linear": (_i, [_p, _i, _i, _f, _p, _p, _p, _p, _l, _p, _l, _p]),

@@ -709,6 +709,21 @@ static bool pp_fill_problem(PPProblem& pr, bool a_ks, bool b_ks, int64_t M, int6
 
 /* Several independent products C_i = op(A_i).op(B_i) (same operand layouts, input and output types) as ONE launch of the persistent
  * kernel where their shapes tile it; otherwise one launch each. */
+// 1 if mafed_gemm_grouped would run these `n` products (dense operands: lda / ldb = the contiguous extent) as ONE persistent launch whose
+// epilogue emits the squares of C (mafed_gemm_problem.sumsq fused), 0 if they would be taken in a pass over C behind the product(s).
+extern "C" int mafed_gemm_grouped_fuses_sumsq(mafed_dtype in_dtype, int transA, int transB, mafed_dtype c_dtype, const int64_t* M, const int64_t* N,
+                                              const int64_t* K, int n) {
+  if (!M || !N || !K || n < 1 || n > PP_MAXP || in_dtype != MAFED_BF16 || c_dtype != MAFED_F32) return 0;
+  if (!((g_gemm_variant == 0 && g_gemm_pp) || g_gemm_pp_force >= 0)) return 0;
+  const bool a_ks = transA != 0, b_ks = transB == 0;
+  if (!(a_ks && b_ks)) return 0;
+  int64_t ldas[PP_MAXP], ldbs[PP_MAXP];
+  for (int i = 0; i < n; ++i) { ldas[i] = M[i]; ldbs[i] = N[i]; }
+  double fill = 0.0;
+  const int cfg = gemm_pp_pick(a_ks, b_ks, c_dtype, n, M, N, K, ldas, ldbs, g_gemm_pp_force, &fill);
+  return cfg != PP_NONE && cfg != PP_256x256 && (g_gemm_pp_force >= 0 || fill >= 0.7) ? 1 : 0;
+}
+
 extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, mafed_dtype c_dtype, const mafed_gemm_problem* problems, int n,
                                   void* stream) {
   MAFED_CHECK_ARG(problems && n >= 1, "gemm_grouped: no problems");
@@ -736,14 +751,29 @@ extern "C" int mafed_gemm_grouped(mafed_dtype in_dtype, int transA, int transB, 
     double fill = 0.0;
     cfg = gemm_pp_pick(a_ks, b_ks, c_dtype, n, Ms, Ns, Ks, ldas, ldbs, g_gemm_pp_force, &fill);
     one = cfg != PP_NONE && (g_gemm_pp_force >= 0 || fill >= 0.7);
-    for (int i = 0; one && i < n; ++i)
-      if (problems[i].sumsq && cfg == PP_256x256) one = false;   // (gemm_z.hip carries no fused squares)
   }
   if (one) {
+    // gemm_z.hip (256 x 256 tiles: the h = 768 / 2048 weight gradients) carries no fused squares: the group still goes out as ONE launch and
+    // the squares are taken in a pass over each C behind it (round 4 first sent such a group back to one launch per product: 96 launches
+    // instead of 12 at the 1.4B shape, 295 -> 246 samples/s)
+    bool squares_after = false;
+    if (cfg == PP_256x256)
+      for (int i = 0; i < n; ++i)
+        if (pr[i].sumsq) {
+          MAFED_CHECK_ARG(problems[i].ldc == problems[i].N, "gemm_grouped: sumsq needs a dense fp32 C");
+          pr[i].sumsq = nullptr;
+          squares_after = true;
+        }
     const int rc = gemm_pp_launch(cfg, a_ks, b_ks, c_dtype, pr, n, Ms, Ns, Ks, as_stream(stream), want_tickets);
     if (rc != MAFED_OK) return rc;
     MAFED_CHECK_LAUNCH("gemm_grouped(ping-pong)");
     ++g_gemm_pp_launches;
+    if (squares_after)
+      for (int i = 0; i < n; ++i)
+        if (problems[i].sumsq) {
+          const int rc2 = mafed_sumsq_accumulate((const float*)problems[i].C, problems[i].M * problems[i].N, problems[i].sumsq, stream);
+          if (rc2 != MAFED_OK) return rc2;
+        }
     return MAFED_OK;
   }
   for (int i = 0; i < n; ++i) {

@@ -41,7 +41,9 @@ __device__ __forceinline__ f32x4 pp_acc_read(const f32x4& a) {
 // leaving the activation code out keeps those kernels below the register count at which hipcc starts to spill (3 VGPRs with the
 // polynomial GELU compiled in -- a spill anywhere puts a vmcnt(0) into the K loop).  The dispatcher never sends them anything else
 // (pp_fill_problem).
-template <int MT, int NT, typename CT, bool ACC_AGPR = false, bool PLAIN_ONLY = false>
+// SUMSQ: the weight-gradient epilogue also folds the squares of what it stores into cq.sumsq (off for the 256 x 256-tile kernel: with it
+// compiled in, gemm_z_kernel<true, true, float> spilled 492 bytes and its launches took 357 instead of 284 us at the 1.4B shape)
+template <int MT, int NT, typename CT, bool ACC_AGPR = false, bool PLAIN_ONLY = false, bool SUMSQ = PLAIN_ONLY>
 struct PPEpilogue {
   static constexpr bool PAIR = sizeof(CT) == 2;
   static constexpr int NPAIR = NT / 2;
@@ -166,7 +168,7 @@ struct PPEpilogue {
         }
         if constexpr (PAIR) store8(C + o, v);
         else store4(C + o, make_float4(v[0], v[1], v[2], v[3]));
-        if constexpr (PLAIN_ONLY && !PAIR) ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if constexpr (PLAIN_ONLY && !PAIR && SUMSQ) ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         if (colsum) {
 #pragma unroll
           for (int e = 0; e < GW; ++e) cs[e] += v[e];
@@ -182,7 +184,7 @@ struct PPEpilogue {
         }
       }
     }
-    if constexpr (PLAIN_ONLY && !PAIR) {
+    if constexpr (PLAIN_ONLY && !PAIR && SUMSQ) {
       if (cq.sumsq) {   // one float atomic per wave and tile, spread over 16 slots by (tile column, tile row)
         ssq = wave_sum(ssq);
         if (lane == 0) atomicAdd(cq.sumsq + (int)(((colw >> 5) + (row0 >> 7)) & 15), ssq);

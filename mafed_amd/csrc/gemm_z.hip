@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void gemm_z_kernel(PPArgs args_by_value) {
     }
     trace_event(1);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> first non-MFMA reader: up to 18 wait states, none inserted for asm
-    PPEpilogue<MT, NT, CT, true, (A_KS && B_KS)>::run(acc, cq, (int64_t)tm * TM + wr * 128 + li, (int64_t)tn * TN + wc * 128, lane,
+    PPEpilogue<MT, NT, CT, true, (A_KS && B_KS), false>::run(acc, cq, (int64_t)tm * TM + wr * 128 + li, (int64_t)tn * TN + wc * 128, lane,
                                 reinterpret_cast<float*>(smem + NSTG * STAGE) + wave * 128);
     trace_event(2);
     first = false;

@@ -717,6 +717,19 @@ class VLPythiaForCausalLM(nn.Module):
         S = sv["S"]
         return {l: t.view(sv["B"], S, -1) for l, t in taps.items()}
 
+    def _dw_group_fuses_squares(self, rows: int) -> bool:
+        """Will a grouped weight-gradient launch of this model (``dw_group_layers`` layers x four matrices, K = rows) emit the squares of
+        its outputs from the epilogue?  Asked of the library once per (rows, group size)."""
+        cache = self.__dict__.setdefault("_dw_fuse_cache", {})
+        key = (int(rows), int(getattr(self, "dw_group_layers", 2) or 0))
+        if key not in cache:
+            cfg = self.config
+            h, f = cfg.hidden_size, cfg.intermediate_size
+            per_layer = [(3 * h, h, rows), (h, h, rows), (f, h, rows), (h, f, rows)]
+            n_layers = max(1, min(4, key[1]))
+            cache[key] = bool(key[1]) and ops.gemm_grouped_fuses_sumsq(per_layer * n_layers, True, False)
+        return cache[key]
+
     def _engine_backward(self, sv, dloss: Optional[torch.Tensor], dhidden: Sequence[Optional[torch.Tensor]], taps=None):
         # Data parallel, last micro-batch of a window: RCCL's all-reduce kernels hold a workgroup per channel for milliseconds while this
         # backward runs.  The persistent GEMMs assume all 256 of their blocks are resident at once -- with 8 CUs taken the late blocks run
@@ -801,6 +814,8 @@ class VLPythiaForCausalLM(nn.Module):
         # squares of the final matrix gradients from the weight-gradient epilogues (FlatAdamW.begin_incremental_norm): only a sweep whose
         # products all go through the grouped call can promise them -- it records its serial, the norm hook checks it
         dw_sq = getattr(self, "dw_sumsq", None) if (group_dw and taps is None) else None
+        if dw_sq is not None and not self._dw_group_fuses_squares(sv["B"] * sv["S"]):
+            dw_sq = None   # (h = 768 / 2048: the 256 x 256-tile kernel has no fused squares -- the norm hook's range pass is cheaper than a pass per matrix)
         self._dw_sumsq_used = self._bw_serial if dw_sq is not None else None
         DW_SLOT = {"attention.query_key_value.weight": 0, "attention.dense.weight": 1, "mlp.dense_h_to_4h.weight": 2, "mlp.dense_4h_to_h.weight": 3}
         pending_dw: List[dict] = []

@@ -5,7 +5,7 @@ there is deliberately no CPU implementation behind these names.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -317,6 +317,17 @@ def attn_decode(qkv_prefix: torch.Tensor, S0: int, qkv_new: torch.Tensor, t: int
     check(fn(_ptr(qkv_prefix), S0, _ptr(qkv_new), cap, t, _dt(qkv_new), B, H, D, rot, _ptr(cos), _ptr(sin),
              _ptr(attention_mask), attention_mask.shape[1], _ptr(out), _stream()), "mafed_attn_decode")
     return out
+
+
+def gemm_grouped_fuses_sumsq(shapes: Sequence[Tuple[int, int, int]], transA: bool, transB: bool) -> bool:
+    """Would ``gemm_grouped`` run these (M, N, K) bf16 -> fp32 products as one persistent launch with the squares of C fused into its
+    epilogue?  (host-side query, no launch)"""
+    import ctypes
+    n = len(shapes)
+    arr = lambda k: (ctypes.c_int64 * n)(*[int(s[k]) for s in shapes])
+    Ms, Ns, Ks = arr(0), arr(1), arr(2)
+    return bool(_lib.load().mafed_gemm_grouped_fuses_sumsq(_lib.BF16, int(transA), int(transB), _lib.F32, ctypes.cast(Ms, ctypes.c_void_p),
+                                                           ctypes.cast(Ns, ctypes.c_void_p), ctypes.cast(Ks, ctypes.c_void_p), n))
 
 
 def decode_supported(M: int, h: int, n1: int) -> bool:

@@ -153,22 +153,27 @@ def test_non_finite_gradient_norm_skips_the_update():
 
 
 # ---- squares of the weight gradients from the GEMM epilogue (mafed_gemm_problem.sumsq) ---------------------------------------------
-@pytest.mark.parametrize("shape", [(1024, 1024, 4608), (3072, 1024, 2304), (192, 64, 96)])
+@pytest.mark.parametrize("shape", [(1024, 1024, 4608), (3072, 1024, 2304), (192, 64, 96), (2048, 2048, 2304), (768, 2304, 2304)])
 @pytest.mark.parametrize("beta", [0.0, 1.0])
 def test_grouped_gemm_leaves_the_squares_of_c(shape, beta):
     """sum of the 16 slots += sum C^2 of the stored C: fused into the persistent weight-gradient kernel where the shapes tile it
-    (first two), a pass over C behind the product otherwise (third)."""
-    from mafed_amd import ops
+    (first two), a pass over C behind the product otherwise (third; and the 256 x 256-tile kernel's shapes, h = 2048 / 768, where the
+    group must still go out as ONE persistent launch -- the regression this guards sent it back to one launch per product)."""
+    from mafed_amd import ops, _lib
     M, N, K = shape
+    launches0 = _lib.load().mafed_gemm_pp_launches()
     g = torch.Generator(device=DEV).manual_seed(5)
     probs = []
-    for i in range(2):
+    big = M * N >= 768 * 2304      # the 256 x 256-tile kernel's shapes: eight products fill the chip (one persistent launch)
+    for i in range(8 if big else 2):
         A = (torch.randn(K, M, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
         B = (torch.randn(K, N, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
         out = torch.randn(M, N, device=DEV, generator=g)
         probs.append(dict(A=A, B=B, out=out, beta=beta, sumsq=torch.full((16,), 0.5 * i, device=DEV)))
     ops.gemm_grouped(probs, True, False)
     torch.cuda.synchronize()
+    if big and shape != (3072, 1024, 2304):
+        assert _lib.load().mafed_gemm_pp_launches() - launches0 == 1, "the group left the persistent path"
     for i, q in enumerate(probs):
         want = float((q["out"].double() ** 2).sum()) + 16 * 0.5 * i
         got = float(q["sumsq"].double().sum())
@@ -217,3 +222,16 @@ def test_fused_norm_squares_give_the_same_clip_norm_at_410m():
     for a, b, c in zip(norms["fused"], norms["partials"], norms["onepass"]):
         assert abs(a - c) <= 2e-3 * c and abs(b - c) <= 2e-3 * c, norms   # (2e-3: the run-to-run noise of a bf16 backward's atomics)
     assert abs(norms["fused"][0] - norms["partials"][0]) <= 2e-3 * norms["partials"][0]
+
+
+def test_fused_squares_are_only_promised_where_the_launch_emits_them():
+    """Host query behind model._dw_group_fuses_squares: the 410M group (two layers, 128 x 256 tiles) fuses the squares; the h = 768 / 2048
+    groups run on the 256 x 256-tile kernel, which does not -- there the norm hook keeps its range pass (the regression this guards cost the
+    160M / 1.4B-shape steps 15 - 25 %)."""
+    from mafed_amd import ops
+    rows = 32 * 288
+    layer = lambda h: [(3 * h, h, rows), (h, h, rows), (4 * h, h, rows), (h, 4 * h, rows)]
+    assert ops.gemm_grouped_fuses_sumsq(layer(1024) * 2, True, False)
+    assert not ops.gemm_grouped_fuses_sumsq(layer(2048) * 2, True, False)
+    assert not ops.gemm_grouped_fuses_sumsq(layer(768) * 2, True, False)
+    assert not ops.gemm_grouped_fuses_sumsq(layer(1024)[:1], True, False)      # one small product does not fill the chip
