@@ -214,6 +214,27 @@ size_t mafed_decode_out_workspace_bytes(int M, int h);
 int mafed_decode_out(const float* x, float* x_out, int M, int h, int n1, const void* ao, const void* act, const void* wd,
                      const float* bd, const void* w2, const float* b2, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- decode step as ONE launch (csrc/decode_flow.hip) ------------------------------------------------------------------
+ * Every layer's work items (LayerNorm rows, 16-column strips of [q|k|v|4h], (batch, head) attention slices, K-slices of [dense|fc2]) and
+ * the LM head are workgroups of one grid in dependency order that hand over through arrival counters in device memory; a workgroup
+ * requests its weights / cached K|V rows before it waits for its inputs.  Same arithmetic as the three-launch layer above (bf16 weights
+ * and activations, fp32 residual stream, deterministic summation orders).  Shapes: mafed_decode_flow_supported (h = 1024, head size 64,
+ * M <= 32 rows, n1 % 512 == 0, <= 768 keys).
+ *   layers  device array of L + 1 records of 14 pointers: {ln1_w, ln1_b, ln2_w, ln2_b, wqkv, bqkv, w1, b1, wd, bd, w2, b2, kv_prefix,
+ *           kv_new}; record L describes the head: ln1_w / ln1_b = final LayerNorm, wqkv = embed_out [V, h], the rest unused
+ *   x       [32, h] fp32: rows < M hold the embedded tokens on entry (updated in place); ln1 / ln2 / ao [32, h], act [32, n1] bf16 scratch
+ *   flags   mafed_decode_flow_flag_bytes(L) bytes, ZERO-FILLED before every call; its last word is an error flag (non-zero: a hand-over
+ *           timed out -- the results of that step are undefined)
+ *   kv_*    the pre-rotated cache of mafed_attn_decode_prerot; row t of every kv_new receives this step's q | k | v (k rotated)
+ *   logits  [M, V] bf16 */
+int mafed_decode_flow_supported(int M, int h, int n1, int H, int D, int V, int nk);
+size_t mafed_decode_flow_flag_bytes(int L);
+size_t mafed_decode_flow_workspace_bytes(int h, int n1);
+int mafed_decode_flow_step(const void* layers, int L, int M, int h, int n1, int H, int D, int S0, int cap, int t, int rot, int P, int T, int V,
+                           float eps, float* x, void* ln1, void* ln2, void* act, void* ao, void* workspace, size_t workspace_bytes,
+                           void* flags, size_t flag_bytes, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask,
+                           void* logits, void* stream);
+
 /* ---- online EWC penalty (mafed/methods/ewc.py:105-127) -------------------------------------
  * The reference's compute_regularization over named_parameters(), on the flat fp32 buffers:
  *   fwd: out[0] = beta * out[0] + half_lambda * sum_i fisher[i] * (p[i] - p_old[i])^2     (half_lambda = 0.5 * reg_lambda;

@@ -38,6 +38,10 @@ SIGNATURES = {
     "mafed_decode_ln_linear": (_i, [_p, _i, _i, _f, _p, _p, _p, _p, _l, _p, _l, _p]),
     "mafed_decode_out_workspace_bytes": (_z, [_i, _i]),
     "mafed_decode_out": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "mafed_decode_flow_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "mafed_decode_flow_flag_bytes": (_z, [_i]),
+    "mafed_decode_flow_workspace_bytes": (_z, [_i, _i]),
+    "mafed_decode_flow_step": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _z, _p, _z, _p, _p, _p, _p, _p]),
     "mafed_ewc_workspace_bytes": (_z, [_l]),
     "mafed_ewc_penalty_fwd": (_i, [_p, _p, _p, _l, _f, _f, _p, _p, _z, _p]),
     "mafed_ewc_penalty_bwd": (_i, [_p, _p, _p, _l, _f, _p, _p, _p]),

@@ -546,6 +546,11 @@ class VLPythiaForCausalLM(nn.Module):
         cos, sin = self.rotary_tables(S0 + cache.cap)
         w = self._w
         x = self._p("gpt_neox.embed_in.weight").index_select(0, tokens)  # fp32 residual stream row
+        if cache.flow is not None:
+            # the whole step as one launch (csrc/decode_flow.hip): work items hand over through arrival counters
+            fl = cache.flow
+            torch.index_select(self._p("gpt_neox.embed_in.weight"), 0, tokens, out=fl.x[:B])
+            return fl.step(S0, cache.cap, t, rot, cfg.num_vision_tokens, cos, sin, cache.attention_mask, cfg.layer_norm_eps)
         if cache.fused:
             # three launches per layer (csrc/decode.hip): [LN1 | LN2] + QKV + fc1/GELU, attention over the pre-rotated cache, and
             # dense + fc2 + both residuals as one product over the concatenated K
@@ -1014,6 +1019,24 @@ class _DecodeCache:
         # fused decode layer (csrc/decode.hip): bf16 mode over the pre-rotated cache, shapes per mafed_decode_supported
         self.fused = bool(fused) and self.prerot and prefix[0].dtype == torch.bfloat16 and ops.decode_supported(B, cfg.hidden_size, cfg.intermediate_size)
         self.workspace = ops.decode_out_workspace(B, cfg.hidden_size, prefix[0].device) if self.fused else None
+        # opt-in (`model.flow_decode = True`): the whole step as ONE launch whose work items hand over through arrival counters
+        # (csrc/decode_flow.hip).  Correct and deterministic, but measured SLOWER than the three-launch layers (1.46 vs 0.88 ms per step at
+        # 410M / B = 32): a hand-over through the memory side costs more than a kernel boundary in a graph
+        self.flow = None
+        if self.fused and getattr(model, "flow_decode", False) and ops.decode_flow_supported(
+                B, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size, S0 + self.cap):
+            w, p = model._w, model._p
+            recs = []
+            for i in range(cfg.num_hidden_layers):
+                pre = f"gpt_neox.layers.{i}."
+                recs.append([p(pre + "input_layernorm.weight"), p(pre + "input_layernorm.bias"), p(pre + "post_attention_layernorm.weight"),
+                             p(pre + "post_attention_layernorm.bias"), w(pre + "attention.query_key_value.weight"),
+                             p(pre + "attention.query_key_value.bias"), w(pre + "mlp.dense_h_to_4h.weight"), p(pre + "mlp.dense_h_to_4h.bias"),
+                             w(pre + "attention.dense.weight"), p(pre + "attention.dense.bias"), w(pre + "mlp.dense_4h_to_h.weight"),
+                             p(pre + "mlp.dense_4h_to_h.bias"), prefix[i], self.new[i]])
+            recs.append([p("gpt_neox.final_layer_norm.weight"), p("gpt_neox.final_layer_norm.bias"), None, None, w("embed_out.weight")] + [None] * 9)
+            self.flow = ops.DecodeFlow(recs, B, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size,
+                                       prefix[0].device)
         if self.prerot:
             self.rotate_prefix()
 

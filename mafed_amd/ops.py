@@ -387,6 +387,43 @@ def decode_out(x: torch.Tensor, ao: torch.Tensor, act: torch.Tensor, wd: torch.T
     return out
 
 
+class DecodeFlow:
+    """Buffers and the per-layer pointer table of the one-launch decode step (``mafed_decode_flow_step``) for one K/V cache."""
+
+    def __init__(self, layer_ptrs: Sequence[Sequence[torch.Tensor]], M: int, h: int, n1: int, H: int, D: int, V: int, device):
+        lib = _lib.load()
+        self.L = len(layer_ptrs) - 1
+        self.M, self.h, self.n1, self.H, self.D, self.V = M, h, n1, H, D, V
+        tab = [[0 if t is None else _ptr(t) for t in rec] for rec in layer_ptrs]
+        assert all(len(r) == 14 for r in tab)
+        self._keep = layer_ptrs                                   # the table holds raw addresses: keep the tensors alive
+        self.table = torch.tensor(tab, dtype=torch.int64).to(device)
+        z = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=device)
+        self.x = z(32, h, dt=torch.float32)
+        self.ln1, self.ln2, self.ao, self.act = z(32, h), z(32, h), z(32, h), z(32, n1)
+        self.ws = torch.zeros(int(lib.mafed_decode_flow_workspace_bytes(h, n1)), dtype=torch.uint8, device=device)
+        self.flags = torch.zeros(int(lib.mafed_decode_flow_flag_bytes(self.L)) // 4, dtype=torch.int32, device=device)
+        self.logits = z(M, V)
+
+    def step(self, S0: int, cap: int, t: int, rot: int, P: int, cos, sin, attention_mask: torch.Tensor, eps: float) -> torch.Tensor:
+        """x (rows < M filled by the caller) -> logits [M, V] bf16 (a static buffer: consume before the next step)."""
+        self.flags.zero_()
+        check(_lib.load().mafed_decode_flow_step(_ptr(self.table), self.L, self.M, self.h, self.n1, self.H, self.D, S0, cap, t, rot, P,
+                                                 attention_mask.shape[1], self.V, float(eps), _ptr(self.x), _ptr(self.ln1), _ptr(self.ln2),
+                                                 _ptr(self.act), _ptr(self.ao), _ptr(self.ws), self.ws.numel(), _ptr(self.flags),
+                                                 self.flags.numel() * 4, _ptr(cos), _ptr(sin), _ptr(attention_mask), _ptr(self.logits), _stream()),
+              "mafed_decode_flow_step")
+        return self.logits
+
+    def timed_out(self) -> bool:
+        """Host check (synchronises): did a hand-over of the last step time out?"""
+        return bool(int(self.flags[-1].item()) != 0)
+
+
+def decode_flow_supported(M: int, h: int, n1: int, H: int, D: int, V: int, nk: int) -> bool:
+    return bool(_lib.load().mafed_decode_flow_supported(int(M), int(h), int(n1), int(H), int(D), int(V), int(nk)))
+
+
 def embed_concat_fwd(image: torch.Tensor, embed_in: torch.Tensor, input_ids: torch.Tensor, B: int, P: int, T: int) -> torch.Tensor:
     V, h = embed_in.shape
     h0 = torch.empty((B * (P + T), h), dtype=torch.float32, device=embed_in.device)
