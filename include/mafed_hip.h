@@ -228,6 +228,10 @@ int mafed_decode_out(const float* x, float* x_out, int M, int h, int n1, const v
  *   kv_*    the pre-rotated cache of mafed_attn_decode_prerot; row t of every kv_new receives this step's q | k | v (k rotated)
  *   logits  [M, V] bf16 */
 int mafed_decode_flow_supported(int M, int h, int n1, int H, int D, int V, int nk);
+/* tools: workgroups of a step's grid, and a device buffer of 4 int64 per workgroup that the next launches fill with wall-clock stamps
+ * {dispatched, wait over, done} (NULL switches the trace off) */
+int64_t mafed_decode_flow_grid(int L, int M, int h, int n1, int H, int V);
+int mafed_decode_flow_set_trace(void* buf);
 size_t mafed_decode_flow_flag_bytes(int L);
 size_t mafed_decode_flow_workspace_bytes(int h, int n1);
 int mafed_decode_flow_step(const void* layers, int L, int M, int h, int n1, int H, int D, int S0, int cap, int t, int rot, int P, int T, int V,

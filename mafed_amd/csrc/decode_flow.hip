@@ -50,11 +50,12 @@ struct FlowArgs {
   const int64_t* am;
   bf16_t* logits;            // [M, V]
   unsigned* err;
+  long long* trace;          // optional [grid][4] wall-clock stamps (dispatch, wait done, role done): tools/decode_flow_trace.py
   int nL, nAq, nAf, nB, nCa, nCo, per_layer;
 };
 
 // ---- hand-over primitives --------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flow_wait(const unsigned* p, unsigned target, unsigned* err) {
+__device__ __forceinline__ void flow_wait(const unsigned* p, unsigned target, unsigned* err, long long* tr = nullptr) {
   // ONE wave of the block polls (an agent-scope load goes to the memory side: with every wave of 768 resident workgroups polling the same
   // few words the polls queued up in front of the data loads -- 1.62 ms per step against 0.88 for the three-launch layers); the others
   // wait at the barrier
@@ -69,6 +70,7 @@ __device__ __forceinline__ void flow_wait(const unsigned* p, unsigned target, un
     }
   }
   __syncthreads();
+  if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
   asm volatile("" ::: "memory");
 }
 // after the block's agent-scope stores: they have left, then the counter moves
@@ -134,7 +136,7 @@ __device__ __forceinline__ void flow_ln(const FlowArgs& a, const FlowLayer& ly, 
   unsigned* fl = a.flags + (size_t)layer * FLOW_STRIDE;
   // affine parameters do not depend on anything
   float4 g1[2], o1[2], g2[2], o2[2];   // h = 1024: 16 columns per lane = pieces jj = 0 .. 3 of 4 floats; held as two halves to bound registers
-  if (layer > 0) flow_wait(fl + FLOW_XR, (unsigned)(h / 32), a.err);
+  if (layer > 0) flow_wait(fl + FLOW_XR, (unsigned)(h / 32), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
   if (row < a.M) {
     uint4 raw[4];
     ld4_sc1<1024>(reinterpret_cast<const char*>(a.x + (size_t)row * h) + lane * 16, raw);
@@ -196,7 +198,7 @@ __device__ __forceinline__ void flow_strip(const FlowArgs& a, const FlowLayer& l
   const float* bias = kind == 0 ? ly.bqkv : (kind == 1 ? ly.b1 : nullptr);
   float4 bia = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) bia = load4(bias + n0 + 4 * g);   // (uniform branch)
-  flow_wait(fl + FLOW_LN, (unsigned)a.nL, a.err);
+  flow_wait(fl + FLOW_LN, (unsigned)a.nL, a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
   const bf16_t* X = kind == 1 ? a.ln2 : a.ln1;
   uint4 xa[8], xb[8];
   ld2x8_sc1(X + (size_t)i * h + kb, X + (size_t)((MT > 1 ? 16 : 0) + i) * h + kb, xa, xb);
@@ -276,7 +278,7 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowLayer& ly
     vraw[u] = *reinterpret_cast<const uint4*>(row + 2 * D + c * 8);
   }
   if (tid < Tm) msk[tid] = mword != 0;
-  flow_wait(fl + FLOW_HEAD + hh, (unsigned)(3 * D / 16), a.err);
+  flow_wait(fl + FLOW_HEAD + hh, (unsigned)(3 * D / 16), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
   const bf16_t* qrow = neu + (int64_t)t * rstride;
   uint4 nw[5];
   ld5_sc1(qrow + c * 8, qrow + cpart * 8, qrow + D + c * 8, qrow + D + cpart * 8, qrow + 2 * D + c * 8, nw);
@@ -379,8 +381,8 @@ __device__ __forceinline__ void flow_out(const FlowArgs& a, const FlowLayer& ly,
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int u = 0; u < 4; ++u) wf[s][u] = *reinterpret_cast<const bf16x8*>(Wsrc + (size_t)(n0 + 16 * s + i) * ld + kq + 128 * u);
-  if (is_ao) flow_wait(fl + FLOW_AO + slice, (unsigned)((512 / 64) * a.M), a.err);
-  else flow_wait(fl + FLOW_AR + (slice - nao), 32u, a.err);
+  if (is_ao) flow_wait(fl + FLOW_AO + slice, (unsigned)((512 / 64) * a.M), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
+  else flow_wait(fl + FLOW_AR + (slice - nao), 32u, a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
   uint4 xa[4], xb[4];
   ld2x4_sc1(Xsrc + (size_t)i * ld + kq, Xsrc + (size_t)((MT > 1 ? 16 : 0) + i) * ld + kq, xa, xb);
   f32x4 acc[2][MT];
@@ -419,7 +421,7 @@ __device__ __forceinline__ void flow_out(const FlowArgs& a, const FlowLayer& ly,
     *s_last = old == (unsigned)(P - 1);
   }
   __syncthreads();
-  if (!*s_last) return;
+  if (!*s_last) return;   // (block-uniform)
   if (emt < MT) {
     const float4 c0 = load4(ly.bd + nn), c1 = load4(ly.b2 + nn);
     float r[4], sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -457,34 +459,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   int* s_last = reinterpret_cast<int*>(lds_raw + 4 * 2 * MT * 64 * 16);
   const int bid = blockIdx.x;
   const int body = a.L * a.per_layer;
+  long long* tr = a.trace ? a.trace + (size_t)bid * 4 : nullptr;
+  if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
   if (bid < body) {
     const int layer = bid / a.per_layer;
     int r = bid - layer * a.per_layer;
     const FlowLayer ly = a.layers[layer];
-    if (r < a.nL) { flow_ln(a, ly, layer, r, false); return; }
-    r -= a.nL;
-    if (r < a.nAq) { flow_strip<MT>(a, ly, layer, 0, r, red); return; }
-    r -= a.nAq;
-    if (r < a.nAf) { flow_strip<MT>(a, ly, layer, 1, r, red); return; }
-    r -= a.nAf;
-    if (r < a.nB) { flow_attn<UNR>(a, ly, layer, r, reinterpret_cast<float*>(lds_raw)); return; }
-    r -= a.nB;
     const int groups = a.h / 32, nao = a.h / 512;
-    if (r < a.nCa) { flow_out<MT>(a, ly, layer, r % groups, nao + r / groups, red, s_last); return; }   // fc2 slices first: they wait for strips only
-    r -= a.nCa;
-    flow_out<MT>(a, ly, layer, r % groups, r / groups, red, s_last);
-    return;
+    if (r < a.nL) flow_ln(a, ly, layer, r, false);
+    else if ((r -= a.nL) < a.nAq) flow_strip<MT>(a, ly, layer, 0, r, red);
+    else if ((r -= a.nAq) < a.nAf) flow_strip<MT>(a, ly, layer, 1, r, red);
+    else if ((r -= a.nAf) < a.nB) flow_attn<UNR>(a, ly, layer, r, reinterpret_cast<float*>(lds_raw));
+    else if ((r -= a.nB) < a.nCa) flow_out<MT>(a, ly, layer, r % groups, nao + r / groups, red, s_last);   // fc2 slices first: they wait for strips only
+    else { r -= a.nCa; flow_out<MT>(a, ly, layer, r % groups, r / groups, red, s_last); }
+  } else {
+    const FlowLayer ly = a.layers[a.L];
+    int r = bid - body;
+    if (r < a.nL) flow_ln(a, ly, a.L, r, true);
+    else flow_strip<MT>(a, ly, a.L, 2, r - a.nL, red);
   }
-  const FlowLayer ly = a.layers[a.L];
-  int r = bid - body;
-  if (r < a.nL) { flow_ln(a, ly, a.L, r, true); return; }
-  r -= a.nL;
-  flow_strip<MT>(a, ly, a.L, 2, r, red);
+  if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
 }
 
 }  // namespace mafed
 
 using namespace mafed;
+
+static long long* g_flow_trace = nullptr;   // tools: [grid][4] stamps per workgroup of the next launches (mafed_decode_flow_set_trace)
+extern "C" int mafed_decode_flow_set_trace(void* buf) { g_flow_trace = (long long*)buf; return MAFED_OK; }
+extern "C" int64_t mafed_decode_flow_grid(int L, int M, int h, int n1, int H, int V) {
+  const int mt = (M + 15) / 16, nl = mt * 4;
+  return (int64_t)L * (nl + 3 * h / 16 + n1 / 16 + M * H + (h / 32) * (n1 / 512) + (h / 32) * (h / 512)) + nl + V / 16;
+}
 
 extern "C" int mafed_decode_flow_supported(int M, int h, int n1, int H, int D, int V, int nk) {
   if (M < 1 || M > 32 || h != 1024 || n1 % 512 != 0 || n1 > 16 * 512 || D != 64 || H * D != h || V % 16 != 0) return 0;
@@ -512,6 +518,7 @@ extern "C" int mafed_decode_flow_step(const void* layers, int L, int M, int h, i
   a.x = x; a.ln1 = (bf16_t*)ln1; a.ln2 = (bf16_t*)ln2; a.act = (bf16_t*)act; a.ao = (bf16_t*)ao; a.ws = (float*)workspace;
   a.flags = (unsigned*)flags;
   a.err = a.flags + (size_t)(L + 1) * FLOW_STRIDE;
+  a.trace = g_flow_trace;
   a.rc = rot_cos; a.rs = rot_sin; a.am = attention_mask; a.logits = (bf16_t*)logits;
   const int mt = (M + 15) / 16;
   a.nL = mt * 4;
