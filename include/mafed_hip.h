@@ -230,7 +230,7 @@ int mafed_decode_out(const float* x, float* x_out, int M, int h, int n1, const v
 int mafed_decode_flow_supported(int M, int h, int n1, int H, int D, int V, int nk);
 /* tools: workgroups of a step's grid, and a device buffer of 4 int64 per workgroup that the next launches fill with wall-clock stamps
  * {dispatched, wait over, done} (NULL switches the trace off) */
-int64_t mafed_decode_flow_grid(int L, int M, int h, int n1, int H, int V);
+size_t mafed_decode_flow_grid(int L, int M, int h, int n1, int H, int V);
 int mafed_decode_flow_set_trace(void* buf);
 size_t mafed_decode_flow_flag_bytes(int L);
 size_t mafed_decode_flow_workspace_bytes(int h, int n1);
@@ -238,6 +238,16 @@ int mafed_decode_flow_step(const void* layers, int L, int M, int h, int n1, int 
                            float eps, float* x, void* ln1, void* ln2, void* act, void* ao, void* workspace, size_t workspace_bytes,
                            void* flags, size_t flag_bytes, const float* rot_cos, const float* rot_sin, const int64_t* attention_mask,
                            void* logits, void* stream);
+
+/* Second launch of a decode layer, behind mafed_decode_ln_qkv_fc1: attention over the pre-rotated cache AND x <- x + dense(ao) + fc2(act)
+ * as one grid (fc2 K-slices, then (batch, head) attention slices, then the dense K-slices, which wait for their heads' arrival counter):
+ * the K|V stream and the output weights are requested together.  layer_rec: one record of 14 pointers as in mafed_decode_flow_step
+ * (only wd, bd, w2, b2, kv_prefix, kv_new are read).  act [32, n1] (rows < M from the first launch), ao [32, h] scratch, both bf16;
+ * workspace: mafed_decode_flow_workspace_bytes(h, n1); flags: 1 KB, ZERO on entry (last word: error flag).  Shapes:
+ * mafed_decode_flow_supported. */
+int mafed_decode_attn_out(const void* layer_rec, int M, int h, int n1, int H, int D, int S0, int cap, int t, int rot, int P, int T,
+                          float* x, const void* act, void* ao, void* workspace, size_t workspace_bytes, void* flags,
+                          const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, void* stream);
 
 /* ---- online EWC penalty (mafed/methods/ewc.py:105-127) -------------------------------------
  * The reference's compute_regularization over named_parameters(), on the flat fp32 buffers:

@@ -39,7 +39,8 @@ SIGNATURES = {
     "mafed_decode_out_workspace_bytes": (_z, [_i, _i]),
     "mafed_decode_out": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "mafed_decode_flow_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    "mafed_decode_flow_grid": (_l, [_i, _i, _i, _i, _i, _i]),
+    "mafed_decode_attn_out": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p, _p, _p, _p, _p]),
+    "mafed_decode_flow_grid": (_z, [_i, _i, _i, _i, _i, _i]),
     "mafed_decode_flow_set_trace": (_i, [_p]),
     "mafed_decode_flow_flag_bytes": (_z, [_i]),
     "mafed_decode_flow_workspace_bytes": (_z, [_i, _i]),

@@ -50,6 +50,7 @@ struct FlowArgs {
   const int64_t* am;
   bf16_t* logits;            // [M, V]
   unsigned* err;
+  int chain;                 // 1: the whole step (every hand-over through counters); 0: one layer's attention + K-slices (decode_attn_out_kernel)
   long long* trace;          // optional [grid][4] wall-clock stamps (dispatch, wait done, role done): tools/decode_flow_trace.py
   int nL, nAq, nAf, nB, nCa, nCo, per_layer;
 };
@@ -244,7 +245,7 @@ __device__ __forceinline__ void flow_strip(const FlowArgs& a, const FlowLayer& l
 }
 
 // ---- role B: attention of one (batch, head) slice over the pre-rotated cache (attn_ref.hip: attn_decode_flat_kernel's form) ---------------
-template <int UNR>
+template <int UNR, bool WAIT = true>
 __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowLayer& ly, int layer, int bh, float* lds) {
   constexpr int D = 64, chunks = D / 8, groups = 256 / chunks;
   float(*red)[D + 1] = reinterpret_cast<float(*)[D + 1]>(lds);      // [4][D + 1]
@@ -278,7 +279,8 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowLayer& ly
     vraw[u] = *reinterpret_cast<const uint4*>(row + 2 * D + c * 8);
   }
   if (tid < Tm) msk[tid] = mword != 0;
-  flow_wait(fl + FLOW_HEAD + hh, (unsigned)(3 * D / 16), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
+  if constexpr (WAIT) flow_wait(fl + FLOW_HEAD + hh, (unsigned)(3 * D / 16), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
+  else __syncthreads();   // (row t was written by the previous launch; the barrier only publishes the mask bytes early)
   const bf16_t* qrow = neu + (int64_t)t * rstride;
   uint4 nw[5];
   ld5_sc1(qrow + c * 8, qrow + cpart * 8, qrow + D + c * 8, qrow + D + cpart * 8, qrow + 2 * D + c * 8, nw);
@@ -363,7 +365,7 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowLayer& ly
 }
 
 // ---- role C: a 512-deep K-slice of 32 columns of x + dense(ao) + fc2(act); the last slice of a column group to arrive reduces ----------
-template <int MT>
+template <int MT, bool WAIT = true>
 __device__ __forceinline__ void flow_out(const FlowArgs& a, const FlowLayer& ly, int layer, int grp, int slice, f32x4* red, int* s_last) {
   // slice: index into the concatenated K in units of 512 (slices < h / 512 read ao . Wd, the others act . W2)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,10 +383,18 @@ __device__ __forceinline__ void flow_out(const FlowArgs& a, const FlowLayer& ly,
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int u = 0; u < 4; ++u) wf[s][u] = *reinterpret_cast<const bf16x8*>(Wsrc + (size_t)(n0 + 16 * s + i) * ld + kq + 128 * u);
-  if (is_ao) flow_wait(fl + FLOW_AO + slice, (unsigned)((512 / 64) * a.M), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
-  else flow_wait(fl + FLOW_AR + (slice - nao), 32u, a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
   uint4 xa[4], xb[4];
-  ld2x4_sc1(Xsrc + (size_t)i * ld + kq, Xsrc + (size_t)((MT > 1 ? 16 : 0) + i) * ld + kq, xa, xb);
+  if constexpr (WAIT) {
+    if (is_ao) flow_wait(fl + FLOW_AO + slice, (unsigned)((512 / 64) * a.M), a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
+    else flow_wait(fl + FLOW_AR + (slice - nao), 32u, a.err, a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr);
+    ld2x4_sc1(Xsrc + (size_t)i * ld + kq, Xsrc + (size_t)((MT > 1 ? 16 : 0) + i) * ld + kq, xa, xb);
+  } else {   // the operand was written by the previous launch: plain (L2-cached) loads, nothing to wait for
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xa[u] = *reinterpret_cast<const uint4*>(Xsrc + (size_t)i * ld + kq + 128 * u);
+      xb[u] = *reinterpret_cast<const uint4*>(Xsrc + (size_t)((MT > 1 ? 16 : 0) + i) * ld + kq + 128 * u);
+    }
+  }
   f32x4 acc[2][MT];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -433,14 +443,26 @@ __device__ __forceinline__ void flow_out(const FlowArgs& a, const FlowLayer& ly,
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = 0.f;
     }
-    for (int pp = 0; pp < P; ++pp) {   // slice order, whichever block happens to be last
-      const float* rp = a.ws + ((size_t)pp * 32 + m) * h + nn;
-      float tv[4];
+    // all P <= 16 slices requested at once (clamped index: not a dependent round trip per slice), added in slice order whichever block
+    // happens to be last
+    float tv[16][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tv[e] = ld_sc1(rp + e);
+    for (int pp = 0; pp < 16; ++pp) {
+      const float* rp = a.ws + ((size_t)(pp < P ? pp : 0) * 32 + m) * h + nn;
+      if (pp < 12 || P > 12) {   // (P = 10 at 410M: twelve loads in flight)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sum[e] += tv[e];
+        for (int e = 0; e < 4; ++e) tv[pp][e] = ld_sc1(rp + e);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tv[pp][e] = 0.f;
+      }
     }
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp)
+      if (pp < P) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += tv[pp][e];
+      }
     if (m < a.M) {
       float* xo = a.x + (size_t)m * h + nn;
       st_sc1(xo + 0, r[0] + (sum[0] + c0.x + c1.x));
@@ -449,7 +471,7 @@ __device__ __forceinline__ void flow_out(const FlowArgs& a, const FlowLayer& ly,
       st_sc1(xo + 3, r[3] + (sum[3] + c0.w + c1.w));
     }
   }
-  flow_signal(a.flags + (size_t)(layer + 1) * FLOW_STRIDE + FLOW_XR);
+  if (a.chain) flow_signal(a.flags + (size_t)(layer + 1) * FLOW_STRIDE + FLOW_XR);
 }
 
 template <int MT, int UNR>
@@ -481,15 +503,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
 }
 
+// One layer's attention and [dense|fc2] product as ONE launch behind mafed_decode_ln_qkv_fc1 (round 4): the fc2 K-slices (they need
+// only the previous launch's activation row) come first in id order, then the (batch, head) attention slices, then the dense K-slices,
+// which wait for their eight heads' arrival counter.  The K|V stream (38.5 MB) and the 10 MB of weights are requested together from the
+// first microsecond; of the 832 workgroups 768 are resident at once, the 64 dense K-slices take the first slots the fc2 slices free.
+template <int MT, int UNR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void decode_attn_out_kernel(FlowArgs a) {
+  __shared__ __align__(16) unsigned char lds_raw[4 * 2 * MT * 64 * 16 + 16];
+  f32x4* red = reinterpret_cast<f32x4*>(lds_raw);
+  int* s_last = reinterpret_cast<int*>(lds_raw + 4 * 2 * MT * 64 * 16);
+  const FlowLayer ly = a.layers[0];
+  const int groups = a.h / 32, nao = a.h / 512;
+  int r = blockIdx.x;
+  long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 4 : nullptr;
+  if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
+  if (r < a.nCa) flow_out<MT, false>(a, ly, 0, r % groups, nao + r / groups, red, s_last);
+  else if ((r -= a.nCa) < a.nB) flow_attn<UNR, false>(a, ly, 0, r, reinterpret_cast<float*>(lds_raw));
+  else { r -= a.nB; flow_out<MT, true>(a, ly, 0, r % groups, r / groups, red, s_last); }
+  if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
+}
+
 }  // namespace mafed
 
 using namespace mafed;
 
 static long long* g_flow_trace = nullptr;   // tools: [grid][4] stamps per workgroup of the next launches (mafed_decode_flow_set_trace)
 extern "C" int mafed_decode_flow_set_trace(void* buf) { g_flow_trace = (long long*)buf; return MAFED_OK; }
-extern "C" int64_t mafed_decode_flow_grid(int L, int M, int h, int n1, int H, int V) {
+extern "C" size_t mafed_decode_flow_grid(int L, int M, int h, int n1, int H, int V) {
   const int mt = (M + 15) / 16, nl = mt * 4;
-  return (int64_t)L * (nl + 3 * h / 16 + n1 / 16 + M * H + (h / 32) * (n1 / 512) + (h / 32) * (h / 512)) + nl + V / 16;
+  return (size_t)L * (nl + 3 * h / 16 + n1 / 16 + M * H + (h / 32) * (n1 / 512) + (h / 32) * (h / 512)) + nl + V / 16;
 }
 
 extern "C" int mafed_decode_flow_supported(int M, int h, int n1, int H, int D, int V, int nk) {
@@ -519,6 +561,7 @@ extern "C" int mafed_decode_flow_step(const void* layers, int L, int M, int h, i
   a.flags = (unsigned*)flags;
   a.err = a.flags + (size_t)(L + 1) * FLOW_STRIDE;
   a.trace = g_flow_trace;
+  a.chain = 1;
   a.rc = rot_cos; a.rs = rot_sin; a.am = attention_mask; a.logits = (bf16_t*)logits;
   const int mt = (M + 15) / 16;
   a.nL = mt * 4;
@@ -534,5 +577,40 @@ extern "C" int mafed_decode_flow_step(const void* layers, int L, int M, int h, i
   else { if (need <= 10) GO(2, 10); else if (need <= 16) GO(2, 16); else GO(2, 24); }
 #undef GO
   MAFED_CHECK_LAUNCH("decode_flow_step");
+  return MAFED_OK;
+}
+
+// Second launch of a decode layer (behind mafed_decode_ln_qkv_fc1): attention over the pre-rotated cache + x <- x + dense(ao) + fc2(act).
+// layer_rec: one record of 14 pointers (see mafed_decode_flow_step; ln / qkv / fc1 entries unused).  act [32, n1], ao [32, h] (scratch) bf16;
+// flags: 1 KB, ZERO on entry (a launch leaves its counters non-zero: one slot per launch, or re-zeroed between uses).
+extern "C" int mafed_decode_attn_out(const void* layer_rec, int M, int h, int n1, int H, int D, int S0, int cap, int t, int rot, int P, int Tm,
+                                     float* x, const void* act, void* ao, void* workspace, size_t workspace_bytes, void* flags,
+                                     const float* rot_cos, const float* rot_sin, const int64_t* attention_mask, void* stream) {
+  MAFED_CHECK_ARG(mafed_decode_flow_supported(M, h, n1, H, D, 16, S0 + t + 1), "decode_attn_out: unsupported shape");
+  MAFED_CHECK_ARG(layer_rec && x && act && ao && workspace && flags && rot_cos && rot_sin && attention_mask, "decode_attn_out: null operand");
+  MAFED_CHECK_ARG(t >= 0 && t < cap && rot % 16 == 0 && Tm >= 1 && Tm <= 256 && S0 >= P, "decode_attn_out: bad step arguments");
+  MAFED_CHECK_ARG(workspace_bytes >= mafed_decode_flow_workspace_bytes(h, n1), "decode_attn_out: workspace too small");
+  FlowArgs a;
+  a.layers = (const FlowLayer*)layer_rec;
+  a.L = 1; a.M = M; a.h = h; a.n1 = n1; a.H = H; a.S0 = S0; a.cap = cap; a.t = t; a.rot = rot; a.P = P; a.Tm = Tm; a.V = 0;
+  a.eps = 0.f;
+  a.x = x; a.ln1 = nullptr; a.ln2 = nullptr; a.act = (bf16_t*)const_cast<void*>(act); a.ao = (bf16_t*)ao; a.ws = (float*)workspace;
+  a.flags = (unsigned*)flags;
+  a.err = a.flags + FLOW_STRIDE - 1;   // last word of the slot
+  a.rc = rot_cos; a.rs = rot_sin; a.am = attention_mask; a.logits = nullptr;
+  a.chain = 0;
+  a.trace = g_flow_trace;
+  const int mt = (M + 15) / 16;
+  a.nL = 0; a.nAq = 0; a.nAf = 0; a.nB = M * H;
+  a.nCa = (h / 32) * (n1 / 512); a.nCo = (h / 32) * (h / 512);
+  a.per_layer = a.nB + a.nCa + a.nCo;
+  const int need = (S0 + t + 1 + 31) / 32;
+  const dim3 grid((unsigned)a.per_layer), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define GO(MTV, UV) decode_attn_out_kernel<MTV, UV><<<grid, block, 0, st>>>(a)
+  if (mt == 1) { if (need <= 10) GO(1, 10); else if (need <= 16) GO(1, 16); else GO(1, 24); }
+  else { if (need <= 10) GO(2, 10); else if (need <= 16) GO(2, 16); else GO(2, 24); }
+#undef GO
+  MAFED_CHECK_LAUNCH("decode_attn_out");
   return MAFED_OK;
 }

@@ -551,6 +551,22 @@ class VLPythiaForCausalLM(nn.Module):
             fl = cache.flow
             torch.index_select(self._p("gpt_neox.embed_in.weight"), 0, tokens, out=fl.x[:B])
             return fl.step(S0, cache.cap, t, rot, cfg.num_vision_tokens, cos, sin, cache.attention_mask, cfg.layer_norm_eps)
+        if cache.pair is not None:
+            # two launches per layer: [LN1 | LN2] + QKV + fc1/GELU (csrc/decode.hip), then attention + dense + fc2 + residuals as one grid
+            # whose dense K-slices wait for the attention slices' arrival counters (csrc/decode_flow.hip: decode_attn_out_kernel)
+            pr = cache.pair
+            pr.begin_step(t)
+            for i in range(L):
+                pre = f"gpt_neox.layers.{i}."
+                ops.decode_ln_qkv_fc1(x, self._p(pre + "input_layernorm.weight"), self._p(pre + "input_layernorm.bias"),
+                                      self._p(pre + "post_attention_layernorm.weight"), self._p(pre + "post_attention_layernorm.bias"),
+                                      cfg.layer_norm_eps, w(pre + "attention.query_key_value.weight"),
+                                      self._p(pre + "attention.query_key_value.bias"), cache.new[i][:, t, :],
+                                      w(pre + "mlp.dense_h_to_4h.weight"), self._p(pre + "mlp.dense_h_to_4h.bias"), a_out=pr.act)
+                pr.run(i, t, x, S0, rot, cfg.num_vision_tokens, cos, sin, cache.attention_mask)
+            lnf, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                             None, None, cfg.layer_norm_eps, cd, save_stats=False)
+            return ops.gemm(lnf, w("embed_out.weight"), False, True)
         if cache.fused:
             # three launches per layer (csrc/decode.hip): [LN1 | LN2] + QKV + fc1/GELU, attention over the pre-rotated cache, and
             # dense + fc2 + both residuals as one product over the concatenated K
@@ -1037,6 +1053,19 @@ class _DecodeCache:
             recs.append([p("gpt_neox.final_layer_norm.weight"), p("gpt_neox.final_layer_norm.bias"), None, None, w("embed_out.weight")] + [None] * 9)
             self.flow = ops.DecodeFlow(recs, B, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, cfg.vocab_size,
                                        prefix[0].device)
+        # opt-in (`model.pair_decode = True`): two launches per layer -- the strips, then attention + [dense|fc2] as one grid with one
+        # hand-over.  Also correct and also slower than the three-launch layers (1.13 vs 0.88 ms per step)
+        self.pair = None
+        if self.fused and self.flow is None and getattr(model, "pair_decode", False) and ops.decode_flow_supported(
+                B, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, 16, S0 + self.cap):
+            w, p = model._w, model._p
+            recs = []
+            for i in range(cfg.num_hidden_layers):
+                pre = f"gpt_neox.layers.{i}."
+                recs.append([None] * 8 + [w(pre + "attention.dense.weight"), p(pre + "attention.dense.bias"), w(pre + "mlp.dense_4h_to_h.weight"),
+                                          p(pre + "mlp.dense_4h_to_h.bias"), prefix[i], self.new[i]])
+            self.pair = ops.DecodeAttnOut(recs, B, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim, self.cap,
+                                          prefix[0].device)
         if self.prerot:
             self.rotate_prefix()
 

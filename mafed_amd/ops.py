@@ -420,6 +420,35 @@ class DecodeFlow:
         return bool(int(self.flags[-1].item()) != 0)
 
 
+class DecodeAttnOut:
+    """Second launch of every decode layer (``mafed_decode_attn_out``): pointer table, scratch rows and one counter slot per (layer, step)."""
+
+    def __init__(self, layer_ptrs: Sequence[Sequence[torch.Tensor]], M: int, h: int, n1: int, H: int, D: int, cap: int, device):
+        lib = _lib.load()
+        self.L, self.M, self.h, self.n1, self.H, self.D, self.cap = len(layer_ptrs), M, h, n1, H, D, cap
+        tab = [[0 if t is None else _ptr(t) for t in rec] for rec in layer_ptrs]
+        assert all(len(r) == 14 for r in tab)
+        self._keep = layer_ptrs                                   # raw addresses in the table: keep the tensors alive
+        self.table = torch.tensor(tab, dtype=torch.int64).to(device)
+        self.act = torch.zeros(32, n1, dtype=torch.bfloat16, device=device)      # first launch writes rows < M
+        self.ao = torch.zeros(32, h, dtype=torch.bfloat16, device=device)
+        self.ws = torch.zeros(int(lib.mafed_decode_flow_workspace_bytes(h, n1)), dtype=torch.uint8, device=device)
+        self.flags = torch.zeros(cap, self.L, 256, dtype=torch.int32, device=device)
+
+    def begin_step(self, t: int) -> None:
+        self.flags[t].zero_()     # the step's counter slots (a launch leaves them non-zero)
+
+    def run(self, i: int, t: int, x: torch.Tensor, S0: int, rot: int, P: int, cos, sin, attention_mask: torch.Tensor) -> None:
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == (self.M, self.h)
+        check(_lib.load().mafed_decode_attn_out(self.table.data_ptr() + i * 14 * 8, self.M, self.h, self.n1, self.H, self.D, S0, self.cap, t, rot, P,
+                                                attention_mask.shape[1], _ptr(x), _ptr(self.act), _ptr(self.ao), _ptr(self.ws), self.ws.numel(),
+                                                self.flags[t, i].data_ptr(), _ptr(cos), _ptr(sin), _ptr(attention_mask), _stream()),
+              "mafed_decode_attn_out")
+
+    def timed_out(self) -> bool:
+        return bool(int(self.flags[:, :, 255].abs().sum().item()) != 0)
+
+
 def decode_flow_supported(M: int, h: int, n1: int, H: int, D: int, V: int, nk: int) -> bool:
     return bool(_lib.load().mafed_decode_flow_supported(int(M), int(h), int(n1), int(H), int(D), int(V), int(nk)))
 

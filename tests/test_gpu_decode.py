@@ -379,3 +379,40 @@ def test_generate_410m_one_launch_decode_tracks_the_three_launch_layers():
     close(st_f[0], st_s[0], 1e-6, "prefill logits")
     if torch.equal(out_f[:, T], out_s[:, T]):
         close(st_f[1], st_s[1], 3e-2, "first cached step: one launch vs three per layer")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("B,T,P", [(32, 12, 64), (5, 9, 40), (17, 32, 256)])
+def test_decode_two_launch_layers_equal_the_three_launch_layers(B, T, P):
+    """Attention + dense + fc2 + residuals as one grid behind the strip launch (mafed_decode_attn_out) against the three-launch layers on
+    the same cache state: logits of three steps, appended cache rows, no time-out, same bits when a step is repeated."""
+    from mafed_amd.model import _DecodeCache
+    cfg, model = _flow_model(P=P)
+    g = torch.Generator().manual_seed(B + 1)
+    ids = torch.randint(1, cfg.vocab_size, (B, T), generator=g).to(DEV)
+    am = torch.ones(B, T, dtype=torch.int64)
+    if B > 1:
+        am[1, : T // 3] = 0
+        am[B - 1, : T // 2] = 0
+    am = am.to(DEV)
+    feats = torch.randn(B, P, cfg.vision_hidden_size, generator=g).to(torch.bfloat16).to(DEV)
+    st = model._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True)
+    pre = [l["qkv"] for l in st["layers"]]
+    model.flow_decode, model.pair_decode = False, True
+    c_pair = _DecodeCache(model, [p.clone() for p in pre], B, st["S"], 4, am)
+    model.pair_decode = False
+    c_ref = _DecodeCache(model, [p.clone() for p in pre], B, st["S"], 4, am)
+    model.pair_decode = True
+    assert c_pair.pair is not None and c_ref.pair is None and c_ref.fused and c_ref.flow is None
+    tok = ids[:, -1].contiguous()
+    for t in range(3):
+        lp = model._engine_decode_step(tok, t, c_pair).float().clone()
+        assert not c_pair.pair.timed_out(), f"step {t}: a hand-over timed out"
+        lr = model._engine_decode_step(tok, t, c_ref).float()
+        close(lp, lr, 2e-2, f"step {t}: logits, two launches vs three per layer")
+        for i in range(cfg.num_hidden_layers):
+            close(c_pair.new[i][:, t, :].float(), c_ref.new[i][:, t, :].float(), 2e-2, f"step {t}, layer {i}: appended cache row")
+        tok = lr.argmax(-1)
+    again = model._engine_decode_step(ids[:, 0].contiguous(), 2, c_pair).float().clone()
+    again2 = model._engine_decode_step(ids[:, 0].contiguous(), 2, c_pair).float()
+    assert torch.equal(again, again2)

@@ -32,28 +32,25 @@ def run(use_cache, reps=5, use_graph=False):
 
 
 t_u, o_u = run(False)
-model.fused_decode = False
-t_e6, _ = run(True)
-t_c6, o_c6 = run(True, use_graph=True)
-model._decode_graphs = {}
-model.fused_decode, model.flow_decode = True, False
-t_e3, _ = run(True)
-t_c3, o_c3 = run(True, use_graph=True)
-model._decode_graphs = {}
-model.flow_decode = True
-t_ef, _ = run(True)
-t_cf, o_cf = run(True, use_graph=True)
-model._decode_graphs = {}
-model.flow_decode = False
-t_e, o_e, t_c, o_c = t_e3, None, t_c3, o_c3
+legs = {}
+for name, fused, flow, pair in (("six launches per layer", False, False, False),
+                                ("one launch per step (opt-in)", True, True, False), ("two launches per layer (opt-in)", True, False, True),
+                                ("three launches per layer", True, False, False)):
+    model._decode_graphs = {}
+    model.fused_decode, model.flow_decode, model.pair_decode = fused, flow, pair
+    t_eager, o_eager = run(True)
+    t_graph, o_graph = run(True, use_graph=True)
+    assert torch.equal(o_eager, o_graph), f"{name}: graph replay and eager launches must produce the same tokens"
+    legs[name] = (t_eager, t_graph, o_graph)
+t_e, t_c, o_c = legs["three launches per layer"]
 same = float((o_u == o_c).float().mean())
-assert torch.equal(run(True)[1], o_c), "graph replay and eager launches must produce the same tokens"
 n_params = sum(p.numel() for p in model.parameters())
 wbytes = 2.0 * (n_params - cfg.vocab_size * cfg.hidden_size)  # bf16 weights streamed per decode step (all but embed_in)
 print(f"{model_name}: generate B={B} {P}+{T} tokens, {NEW} new: recompute {t_u * 1e3:.1f} ms ({B / t_u:.0f} ex/s), "
       f"KV-cached eager {t_e * 1e3:.1f} ms, KV-cached + hipGraph {t_c * 1e3:.1f} ms ({B / t_c:.0f} ex/s), speed-up {t_u / t_c:.2f}x, "
-      f"tokens equal {same:.3f}; one launch per step (opt-in): eager {t_ef * 1e3:.1f} ms, hipGraph {t_cf * 1e3:.1f} ms, tokens equal to the default path {float((o_cf == o_c).float().mean()):.3f}"
-      f"; six launches per layer: eager {t_e6 * 1e3:.1f} ms, hipGraph {t_c6 * 1e3:.1f} ms, tokens equal {float((o_c6 == o_c).float().mean()):.3f}")
+      f"tokens equal {same:.3f}")
+for name, (te, tg, og) in legs.items():
+    print(f"   {name}: eager {te * 1e3:.1f} ms, hipGraph {tg * 1e3:.1f} ms, tokens equal to the default path {float((og == o_c).float().mean()):.3f}")
 # decode-step roofline: the (NEW - 1) cached steps stream the weights once each and every layer's K/V slice once
 from mafed_amd.model import _DecodeCache
 kv_bytes = 0.0
@@ -89,10 +86,11 @@ def step_ms(fused: bool):
     return best, cache.fused
 
 
-for name, fused, flow in (("one launch per step", True, True), ("three launches per layer", True, False), ("six launches per layer", False, False)):
-    model.fused_decode, model.flow_decode = fused, flow
+for name, fused, flow, pair in (("three launches per layer", True, False, False), ("two launches per layer, opt-in", True, False, True),
+                                ("one launch per step, opt-in", True, True, False), ("six launches per layer", False, False, False)):
+    model.fused_decode, model.flow_decode, model.pair_decode = fused, flow, pair
     ms, was_fused = step_ms(fused)
     tot = wbytes + kv_bytes
     print(f"decode step ({name}): {ms:.3f} ms; weights {wbytes / 1e9:.2f} GB + K/V {kv_bytes / 1e9:.2f} GB "
           f"per step -> {tot / ms / 1e9:.2f} TB/s ({tot / ms / 1e9 / 8.0 * 100:.1f} % of 8 TB/s; weights alone {wbytes / ms / 1e9 / 8.0 * 100:.1f} %)")
-model.fused_decode, model.flow_decode = True, False
+model.fused_decode, model.flow_decode, model.pair_decode = True, False, False
