@@ -211,6 +211,8 @@ int mafed_decode_ln_linear(const float* x, int M, int h, float eps, const float*
  * mafed_decode_out_workspace_bytes(M, h) bytes, ZERO-FILLED once before the first call (it holds the arrival counters, which every
  * launch leaves at zero again); one workspace per stream. */
 size_t mafed_decode_out_workspace_bytes(int M, int h);
+/* tools: device buffer of 8 int64 per workgroup that the next mafed_decode_out launches fill with wall-clock stamps (NULL = off) */
+int mafed_decode_set_trace(void* buf);
 int mafed_decode_out(const float* x, float* x_out, int M, int h, int n1, const void* ao, const void* act, const void* wd,
                      const float* bd, const void* w2, const float* b2, void* workspace, size_t workspace_bytes, void* stream);
 

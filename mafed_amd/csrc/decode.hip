@@ -358,6 +358,7 @@ struct DecodeCArgs {
   int P, ksl;              // K slices per column group, k-steps (of 32) per slice
   float* ws;               // [P][MT * 16][h] partial tiles
   unsigned* counters;      // [h / 32], zero between launches
+  long long* trace;        // tools: optional [grid][8] wall-clock stamps per workgroup (mafed_decode_set_trace)
 };
 
 // Everything behind a block's K loop: the four k lanes' tiles are folded through LDS, the block's partial tile goes to the workspace,
@@ -366,19 +367,33 @@ struct DecodeCArgs {
 // around the L2), not with plain stores behind a device-wide fence -- __threadfence() is buffer_wbl2 + buffer_inv of the whole L2 by
 // every wave of every block (measured: 50 us for this kernel instead of 13; fences by one thread per block: 16).  Order: a wave's
 // stores have left (vmcnt(0)) before the block barrier, the arrival counter is bumped after it.
-template <int MT, int NSL>
+// The last block's read-back of the P partial tiles: ONE statement issues a 16-byte agent-scope load per slice (clamped pointer for the
+// slices past P) and waits once -- the dword-at-a-time form (four loads per slice: 48 wave instructions of 16 scattered lines each) took
+// 5.6 us of the kernel's 12 (tools/decode_out_trace.py).
+#define MAFED_LD_SC1(k) "global_load_dwordx4 %" #k ", %[p" #k "], off sc1\n\t"
+__device__ __forceinline__ void ld12_sc1(const float* const (&p)[12], f32x4 (&o)[12]) {
+  asm volatile(MAFED_LD_SC1(0) MAFED_LD_SC1(1) MAFED_LD_SC1(2) MAFED_LD_SC1(3) MAFED_LD_SC1(4) MAFED_LD_SC1(5) MAFED_LD_SC1(6) MAFED_LD_SC1(7)
+               MAFED_LD_SC1(8) MAFED_LD_SC1(9) MAFED_LD_SC1(10) MAFED_LD_SC1(11) "s_waitcnt vmcnt(0)"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+                 "=&v"(o[10]), "=&v"(o[11])
+               : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                 [p8] "v"(p[8]), [p9] "v"(p[9]), [p10] "v"(p[10]), [p11] "v"(p[11])
+               : "memory");
+}
+#undef MAFED_LD_SC1
+// P <= 12 slices in one batch (P = 10 at 410M), up to 24 in two
 __device__ __forceinline__ f32x4 decode_out_sum_slices(const float* __restrict__ ws, int P, int64_t slice_stride, int64_t off) {
-  f32x4 t[NSL];
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int b0 = 0; b0 < P; b0 += 12) {   // (one trip for P <= 12)
+    const float* ptr[12];
 #pragma unroll
-  for (int pp = 0; pp < NSL; ++pp) {   // all requested at once (clamped index), not a dependent round trip to memory per slice
-    const float* rp = ws + (int64_t)(pp < P ? pp : 0) * slice_stride + off;
+    for (int k = 0; k < 12; ++k) ptr[k] = ws + (int64_t)(b0 + k < P ? b0 + k : 0) * slice_stride + off;
+    f32x4 o[12];
+    ld12_sc1(ptr, o);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[pp][r] = __hip_atomic_load(rp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 12; ++k)
+      if (b0 + k < P) v += o[k];   // slice order, whichever block happens to be last (0 + t0 + t1 + ...: the same association every time)
   }
-  f32x4 v = t[0];
-#pragma unroll
-  for (int pp = 1; pp < NSL; ++pp)
-    if (pp < P) v += t[pp];   // slice order, whichever block happens to be last
   return v;
 }
 
@@ -387,6 +402,8 @@ __device__ __forceinline__ void decode_out_finish(const DecodeCArgs& a, const f3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int h = a.h, n0 = grp * 32;
+  long long* tr = a.trace ? a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) red[wave][mt][lane] = acc[mt];
   __syncthreads();
@@ -406,29 +423,28 @@ __device__ __forceinline__ void decode_out_finish(const DecodeCArgs& a, const f3
   if (a.P > 1) {
     if (emt < MT) {
       float* wp = a.ws + ((int64_t)p * Mp + m) * h + nn;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) __hip_atomic_store(wp + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp), "v"(v) : "memory");   // one 16-byte agent-scope store
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+      if (a.trace) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 3] = wall_clock64();
       const unsigned old = __hip_atomic_fetch_add(a.counters + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *s_last = old == (unsigned)(a.P - 1);
+      if (a.trace) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 4] = wall_clock64();
       if (old == (unsigned)(a.P - 1)) __hip_atomic_store(a.counters + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
     }
     __syncthreads();
     if (!*s_last) return;
     if (emt < MT) {
       const int64_t ss = (int64_t)Mp * h, off = (int64_t)m * h + nn;
-      if (a.P <= 4) v = decode_out_sum_slices<MT, 4>(a.ws, a.P, ss, off);
-      else if (a.P <= 8) v = decode_out_sum_slices<MT, 8>(a.ws, a.P, ss, off);
-      else if (a.P <= 12) v = decode_out_sum_slices<MT, 12>(a.ws, a.P, ss, off);
-      else v = decode_out_sum_slices<MT, 16>(a.ws, a.P, ss, off);
+      v = decode_out_sum_slices(a.ws, a.P, ss, off);
     }
   }
   if (emt < MT && m < a.M) {
     store4(a.x_out + (int64_t)m * h + nn, make_float4(r.x + (v[0] + c0.x + c1.x), r.y + (v[1] + c0.y + c1.y), r.z + (v[2] + c0.z + c1.z), r.w + (v[3] + c0.w + c1.w)));
   }
+  if (tr && threadIdx.x == 0) tr[5] = wall_clock64();
 }
 
 // register-direct operands (any served shape): lane (i, g) loads its MFMA fragments straight from global memory
@@ -506,6 +522,8 @@ __global__ __launch_bounds__(512) void decode_out_lds_kernel(DecodeCArgs a) {
   const int ld = first ? h : n1, kofs = first ? k0 : k0 - h;
   const bf16_t* wsrc = (first ? a.wd : a.w2) + (int64_t)n0 * ld + kofs;
   const bf16_t* xsrc = (first ? a.ao : a.act) + kofs;
+  long long* tr0 = a.trace ? a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (tr0 && threadIdx.x == 0) tr0[0] = wall_clock64();
   {
     // wave w moves weight rows w, w + 8, w + 16, w + 24 and activation rows w (, w + 8 ...) -- rows past M re-read row M - 1 (never stored)
     const uint32_t wdst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Ws + (uint32_t)(wave * LDK * 2);
@@ -551,6 +569,7 @@ __global__ __launch_bounds__(512) void decode_out_lds_kernel(DecodeCArgs a) {
     }
   }
   __syncthreads();
+  if (tr0 && threadIdx.x == 0) tr0[1] = wall_clock64();
   const int s = wave & 1, q = wave >> 1;   // strip, k lane (4 per strip)
   f32x4 acc[MT];
 #pragma unroll
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(512) void decode_out_lds_kernel(DecodeCArgs a) {
   decode_out_finish<MT>(a, acc, red, &s_last, grp, p);
 }
 
+long long* g_decode_trace = nullptr;
 int g_decode_lds = 1;    // mafed_gemm_set_variant(760 / 761): register-direct / LDS-staged operand loads
 static int g_num_cus = 0;
 static int num_cus() {
@@ -676,6 +696,9 @@ extern "C" int mafed_decode_ln_linear(const float* x, int M, int h, float eps, c
   return MAFED_OK;
 }
 
+// tools: [grid][8] stamps {entered, operands in LDS, K loop done, partial tile out, counter bumped, left} of the next decode_out launches
+extern "C" int mafed_decode_set_trace(void* buf) { g_decode_trace = (long long*)buf; return MAFED_OK; }
+
 extern "C" size_t mafed_decode_out_workspace_bytes(int M, int h) {
   // [P <= 16][ceil(M / 16) * 16][h] fp32 partial tiles + h / 32 counters (zero-initialised once by the caller; the kernel re-arms them)
   return (size_t)16 * (size_t)(((M + 15) / 16) * 16) * (size_t)h * sizeof(float) + (size_t)(h / 32) * sizeof(unsigned);
@@ -695,7 +718,7 @@ extern "C" int mafed_decode_out(const float* x, float* x_out, int M, int h, int 
   P = (ktot + ksl - 1) / ksl;
   float* ws = (float*)workspace;
   unsigned* counters = (unsigned*)((char*)workspace + (size_t)16 * (size_t)(mt * 16) * (size_t)h * sizeof(float));
-  DecodeCArgs a{x, x_out, M, h, n1, (const bf16_t*)ao, (const bf16_t*)act, (const bf16_t*)wd, (const bf16_t*)w2, bd, b2, P, ksl, ws, counters};
+  DecodeCArgs a{x, x_out, M, h, n1, (const bf16_t*)ao, (const bf16_t*)act, (const bf16_t*)wd, (const bf16_t*)w2, bd, b2, P, ksl, ws, counters, g_decode_trace};
   hipStream_t st = (hipStream_t)stream;
   if (g_decode_lds && mt <= 2 && h == 1024 && n1 % 512 == 0) {   // full-line loads through LDS: 512-deep K slices
     a.ksl = 16;
