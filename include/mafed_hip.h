@@ -213,6 +213,7 @@ int mafed_decode_ln_linear(const float* x, int M, int h, float eps, const float*
 size_t mafed_decode_out_workspace_bytes(int M, int h);
 /* tools: device buffer of 8 int64 per workgroup that the next mafed_decode_out launches fill with wall-clock stamps (NULL = off) */
 int mafed_decode_set_trace(void* buf);
+int mafed_attn_decode_set_trace(void* buf);   /* the same for mafed_attn_decode_prerot's all-rows-in-flight kernel: 8 int64 per (batch, head) */
 int mafed_decode_out(const float* x, float* x_out, int M, int h, int n1, const void* ao, const void* act, const void* wd,
                      const float* bd, const void* w2, const float* b2, void* workspace, size_t workspace_bytes, void* stream);
 

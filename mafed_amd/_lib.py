@@ -38,6 +38,7 @@ SIGNATURES = {
     "mafed_decode_ln_linear": (_i, [_p, _i, _i, _f, _p, _p, _p, _p, _l, _p, _l, _p]),
     "mafed_decode_out_workspace_bytes": (_z, [_i, _i]),
     "mafed_decode_set_trace": (_i, [_p]),
+    "mafed_attn_decode_set_trace": (_i, [_p]),
     "mafed_decode_out": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "mafed_decode_flow_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "mafed_decode_attn_out": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p, _p, _p, _p, _p]),

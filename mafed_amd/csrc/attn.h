@@ -30,4 +30,6 @@ int attn_mfma_bwd_launch(const void* qkv, const void* out, const void* dout, con
 
 void attn_mfma_set_variant(int v);  // 0 automatic (resident kernels when K/V fit in LDS), 1 tiled kernels only
 
+int attn_decode_set_trace(void* buf);   // tools: [B * H][8] stamps of the next flat decode attention launches
+
 }  // namespace mafed

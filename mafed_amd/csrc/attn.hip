@@ -156,3 +156,7 @@ extern "C" int mafed_rotate_k_rows(void* qkv, mafed_dtype dtype, int B, int S, i
   MAFED_CHECK_LAUNCH("rotate_k_rows");
   return MAFED_OK;
 }
+
+// tools: device buffer of 8 int64 per (batch, head) workgroup that the next mafed_attn_decode_prerot launches (all-rows-in-flight form) fill
+// with wall-clock stamps {entered, q | k row rotated, scores done, V sum done, left}; NULL switches it off
+extern "C" int mafed_attn_decode_set_trace(void* buf) { return mafed::attn_decode_set_trace(buf); }

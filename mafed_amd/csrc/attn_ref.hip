@@ -506,6 +506,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const T* __restr
 // nk), so the softmax needs no running state -- scores first, one block-wide max, then exp and the V sum; the row groups are merged with
 // register shuffles inside a wave and four LDS rows across the waves (the online form above merged 32 (m, l, acc) states with 32 dependent
 // expf per output element, and carried two expf per key row).  The prompt mask (Tm <= 256 text positions) is read once into LDS.
+__device__ long long* g_decode_trace_dev = nullptr;   // tools: stamps of the next decode attention launches (mafed_attn_decode_set_trace)
+
 template <int D, int UNR>
 __global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __restrict__ qkv_pre, int S0, bf16_t* __restrict__ qkv_new, int cap, int t,
                                                                int H, int rot, int P, int Tm, const float* __restrict__ rc,
@@ -517,6 +519,8 @@ __global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __r
   __shared__ unsigned char msk[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, b = blockIdx.y;
+  long long* tr = g_decode_trace_dev ? g_decode_trace_dev + ((size_t)b * gridDim.x + h) * 8 : nullptr;
+  if (tr && tid == 0) tr[0] = wall_clock64();
   const int nk = S0 + t + 1;
   const int64_t rstride = (int64_t)H * 3 * D;
   const bf16_t* pre = qkv_pre + ((int64_t)b * S0 * H + h) * 3 * D;
@@ -559,6 +563,7 @@ __global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __r
       knew[e] = inrot ? b0[e] * cs[e] + sgn * b1[e] * sn[e] : b0[e];
     }
   }
+  if (tr && tid == 0) tr[1] = wall_clock64();   // q | k row rotated (first loads back)
   __syncthreads();   // mask bytes; also: every lane has read row t's un-rotated key before the write-back below
   if (tid < chunks) store_row8<bf16_t>(neu + (int64_t)t * rstride + D + tid * 8, knew);   // rotated, for the steps to come (only this block touches the slice)
   float sc[UNR];
@@ -581,6 +586,7 @@ __global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __r
   }
 #pragma unroll
   for (int o = chunks; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+  if (tr && tid == 0) tr[2] = wall_clock64();   // scores done (all K rows in)
   if (lane == 0) wmax[wave] = tmax;
   __syncthreads();
   float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
+  if (tr && tid == 0) tr[3] = wall_clock64();   // V sum and shuffles done
   if (lane < chunks) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[wave][c * 8 + e] = acc[e];
@@ -613,6 +620,7 @@ __global__ __launch_bounds__(256) void attn_decode_flat_kernel(const bf16_t* __r
     const float lt = (red[0][D] + red[1][D]) + (red[2][D] + red[3][D]);
     out[(int64_t)b * H * D + (int64_t)h * D + tid] = f32_to_bf16(lt > 0.f ? o / lt : 0.f);
   }
+  if (tr && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[4] = wall_clock64(); }
 }
 
 // In place: k part of every row of a [B,S,H,3,D] qkv tensor rotated for its position (row index within the sample); rot % 16 == 0.
@@ -650,6 +658,10 @@ template int rotate_k_rows_launch<float>(void*, int64_t, int, int, int, int, con
 template int rotate_k_rows_launch<bf16_t>(void*, int64_t, int, int, int, int, const float*, const float*, hipStream_t);
 
 int g_attn_decode_flat = 1;   // mafed_gemm_set_variant(740 / 741)
+int attn_decode_set_trace(void* buf) {
+  long long* p = (long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_decode_trace_dev), &p, sizeof(p)) == hipSuccess ? MAFED_OK : MAFED_ELAUNCH;
+}
 
 template <typename T>
 int attn_decode_launch(const void* qkv_pre, int S0, const void* qkv_new, int cap, int t, int B, int H, int D, int rot, int P, int Tm,

@@ -21,6 +21,8 @@
 
 namespace mafed {
 
+long long* g_decode_trace = nullptr;   // tools: stamps of the next launches (mafed_decode_set_trace)
+
 struct DecodeAArgs {
   const float* x;        // [M, h] fp32 residual stream
   int M, h;
@@ -34,6 +36,7 @@ struct DecodeAArgs {
   const float* bfc1;
   bf16_t* a_out;         // [M, n1]
   int nqkv, n1;          // 3h, intermediate size
+  long long* trace;      // tools: optional [grid][8] wall-clock stamps (mafed_decode_set_trace)
 };
 
 // lanes (i, g) = (lane & 15, lane >> 4); MFMA 16x16x32: A = W rows n0 + i, k = 8g .. 8g+7; B = x rows (m = i); D[n = 4g + r][m = i]
@@ -197,6 +200,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nqb = a.nqkv / 32;
   const bool is_qkv = (int)blockIdx.x < nqb;
   const int n0 = (is_qkv ? (int)blockIdx.x : (int)blockIdx.x - nqb) * 32;
+  long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+  if (tr && tid == 0) tr[0] = wall_clock64();
   const bf16_t* W = (is_qkv ? a.wqkv : a.w1) + (int64_t)n0 * H;
   const float* gam = is_qkv ? a.g1 : a.g2;
   const float* bet = is_qkv ? a.b1 : a.b2;
@@ -265,31 +270,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef MAFED_DEC_DMA8
   }
-  // row statistics inside the wave, under the slab's flight
-  float mean[RPW], rstd[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    float sm = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < KS; ++jj) sm += (xv[r][jj][0] + xv[r][jj][1]) + (xv[r][jj][2] + xv[r][jj][3]);
-    mean[r] = wave_sum(sm) / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < KS; ++jj) {
-      const float d0 = xv[r][jj][0] - mean[r], d1 = xv[r][jj][1] - mean[r], d2 = xv[r][jj][2] - mean[r], d3 = xv[r][jj][3] - mean[r];
-      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-    rstd[r] = 1.0f / sqrtf(wave_sum(q) / (float)H + a.eps);
-  }
-  // affine parameters and the bias now: these are loads the compiler counts, and any wait it inserts for them (they are the youngest in
-  // the queue) also waits for the slab -- which the barrier below needs anyway
+  if (tr && tid == 0) tr[1] = wall_clock64();   // rows have arrived
+  // affine parameters and the bias: loads the compiler counts (any wait it inserts for them -- they are the youngest in the queue -- also
+  // waits for the slab, which the barrier below needs anyway); requested now, used behind the statistics
   float4 gv[KS], bv[KS];
 #pragma unroll
   for (int jj = 0; jj < KS; ++jj) {
     gv[jj] = load4(gam + 4 * (lane + 64 * jj));
     bv[jj] = load4(bet + 4 * (lane + 64 * jj));
   }
-  const float4 bia = load4(bias + n0 + 16 * es + 4 * g);
+  const float4 bia = bias ? load4(bias + n0 + 16 * es + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);   // (uniform; NULL for the LM head)
+  // row statistics inside the wave, under the slab's flight; the RPW rows are reduced side by side (one row at a time the twelve
+  // dependent cross-lane steps of its two sums were 0.55 us per row: 2.2 of the kernel's 8.8 us, tools/decode_ab_trace.py)
+  float mean[RPW], rstd[RPW], part[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float sm = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KS; ++jj) sm += (xv[r][jj][0] + xv[r][jj][1]) + (xv[r][jj][2] + xv[r][jj][3]);
+    part[r] = sm;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) part[r] += __shfl_xor(part[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    mean[r] = part[r] / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KS; ++jj) {
+      const float d0 = xv[r][jj][0] - mean[r], d1 = xv[r][jj][1] - mean[r], d2 = xv[r][jj][2] - mean[r], d3 = xv[r][jj][3] - mean[r];
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    part[r] = q;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) part[r] += __shfl_xor(part[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) rstd[r] = 1.0f / sqrtf(part[r] / (float)H + a.eps);
+  if (tr && tid == 0) tr[2] = wall_clock64();   // statistics done
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int row = wave + 8 * r;
@@ -301,8 +323,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                          (v[2] - mean[r]) * rstd[r] * gv[jj].z + bv[jj].z, (v[3] - mean[r]) * rstd[r] * gv[jj].w + bv[jj].w));
     }
   }
+  if (tr && tid == 0) tr[3] = wall_clock64();   // normalised rows written
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's slab pieces have landed (the compiler does not count them)
+  if (tr && tid == 0) tr[4] = wall_clock64();   // slab landed
   __syncthreads();
+  if (tr && tid == 0) tr[5] = wall_clock64();
   // wave w multiplies its K slice [w * 32 KS, (w + 1) * 32 KS): both strips x every row block
   const int kb = wave * (KS * 32) + 8 * g;
   f32x4 acc[2][MT];
@@ -322,6 +347,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xf, acc[1][mt], 0, 0, 0);
     }
   }
+  if (tr && tid == 0) tr[6] = wall_clock64();   // MFMAs issued
   __syncthreads();   // every wave has read its operands: the slab's space becomes the partial tiles
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -343,6 +369,135 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         store4(a.a_out + (int64_t)m * a.n1 + n, o);
       }
     }
+  }
+  if (tr && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[7] = wall_clock64(); }
+}
+
+// LM head of a decode step as a persistent kernel (round 4): one 512-thread block per CU normalises the M rows once (final LayerNorm, bf16
+// rows in LDS) and then walks 16-column strips of the vocabulary, the next strip's weight slab (16 rows x 2 KB, global -> LDS) in flight
+// under the current strip's MFMAs.  The one-slab-per-block form above needs six rounds of blocks for V = 50304, each paying its own
+// HBM round trip: 48 us for 103 MB, like LayerNorm + the skinny kernel; this one streams.  h = 1024, M <= 32.
+template <int MT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void decode_head_kernel(DecodeAArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  constexpr int KS = 4, H = 1024, LD = H + 8, MP = 16 * MT;
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);                  // [MP][LD]
+  bf16_t* Wb = Xs + MP * LD;                                        // [2][16][LD]
+  f32x4* red = reinterpret_cast<f32x4*>(Wb + 2 * 16 * LD);           // [8][MT][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int nstrips = a.nqkv / 16;
+  const uint32_t wb0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Wb;
+  const uint32_t dst_w = (uint32_t)((wave >> 1) * (LD * 2) + (wave & 1) * 1024);   // this wave's first piece inside a slab buffer
+  // slab of strip s -> buffer b: four 1 KB pieces per wave (piece w + 8 j: row (w + 8 j) / 2, half (w + 8 j) % 2)
+  auto dma_slab = [&](int s, int b) {
+    const bf16_t* src = a.wqkv + (int64_t)s * 16 * H;
+    uint32_t voff = (uint32_t)(wave * 1024 + lane * 16);
+    const uint32_t dst = wb0 + (uint32_t)(b * 16 * LD * 2) + dst_w;
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %[voff], %[src]\n\ts_add_u32 m0, m0, %[dstep]\n\tv_add_u32 %[voff], 0x2000, %[voff]\n\t"
+                 "global_load_lds_dwordx4 %[voff], %[src]\n\ts_add_u32 m0, m0, %[dstep]\n\tv_add_u32 %[voff], 0x2000, %[voff]\n\t"
+                 "global_load_lds_dwordx4 %[voff], %[src]\n\ts_add_u32 m0, m0, %[dstep]\n\tv_add_u32 %[voff], 0x2000, %[voff]\n\t"
+                 "global_load_lds_dwordx4 %[voff], %[src]\n\ts_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep), [voff] "+v"(voff)
+                 : [src] "s"(src), [dst] "s"(dst), [dstep] "n"(4 * LD * 2)
+                 : "memory", "scc");
+  };
+  int s = blockIdx.x;
+  if (s < nstrips) dma_slab(s, 0);
+  // the block's rows: wave w owns rows w, w + 8, ...; statistics inside the wave, side by side
+  constexpr int RPW = MP / 8;
+  {
+    float4 xv[RPW][KS];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int row = wave + 8 * r;
+      const float* xr = a.x + (int64_t)(row < a.M ? row : 0) * H;
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj) xv[r][jj] = load4(xr + 4 * (lane + 64 * jj));
+    }
+    float4 gv[KS], bv[KS];
+#pragma unroll
+    for (int jj = 0; jj < KS; ++jj) {
+      gv[jj] = load4(a.g1 + 4 * (lane + 64 * jj));
+      bv[jj] = load4(a.b1 + 4 * (lane + 64 * jj));
+    }
+    float mean[RPW], rstd[RPW], part[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      float sm = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj) sm += (xv[r][jj].x + xv[r][jj].y) + (xv[r][jj].z + xv[r][jj].w);
+      part[r] = sm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) part[r] += __shfl_xor(part[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      mean[r] = part[r] / (float)H;
+      float q = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj) {
+        const float d0 = xv[r][jj].x - mean[r], d1 = xv[r][jj].y - mean[r], d2 = xv[r][jj].z - mean[r], d3 = xv[r][jj].w - mean[r];
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      part[r] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) part[r] += __shfl_xor(part[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      rstd[r] = 1.0f / sqrtf(part[r] / (float)H + a.eps);
+      const int row = wave + 8 * r;
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj) {
+        const float4 v = xv[r][jj];
+        store4(Xs + row * LD + 4 * (lane + 64 * jj),
+               make_float4((v.x - mean[r]) * rstd[r] * gv[jj].x + bv[jj].x, (v.y - mean[r]) * rstd[r] * gv[jj].y + bv[jj].y,
+                           (v.z - mean[r]) * rstd[r] * gv[jj].z + bv[jj].z, (v.w - mean[r]) * rstd[r] * gv[jj].w + bv[jj].w));
+      }
+    }
+  }
+  const int kb = wave * (KS * 32) + 8 * g;
+  int buf = 0;
+  for (; s < nstrips; s += gridDim.x, buf ^= 1) {
+    const int sn = s + gridDim.x;
+    if (sn < nstrips) {
+      dma_slab(sn, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything older than the next slab's four pieces: this strip's slab (and the last stores)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();   // slab (and, first trip, the normalised rows) visible to every wave
+    const bf16_t* Ws = Wb + buf * 16 * LD;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + i * LD + kb + 32 * u);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + (mt * 16 + i) * LD + kb + 32 * u);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[mt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    if (wave < MT) {   // wave emt folds row block emt over the eight K slices (fixed order) and stores 16 x 16 logits
+      f32x4 v = red[(0 * MT + wave) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) v += red[(w * MT + wave) * 64 + lane];
+      const int m = wave * 16 + i;
+      if (m < a.M) store4(a.qkv_out + (int64_t)m * a.qkv_ld + (int64_t)s * 16 + 4 * g, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    __syncthreads();   // red and the slab buffer of this trip are free again
   }
 }
 
@@ -588,7 +743,6 @@ __global__ __launch_bounds__(512) void decode_out_lds_kernel(DecodeCArgs a) {
   decode_out_finish<MT>(a, acc, red, &s_last, grp, p);
 }
 
-long long* g_decode_trace = nullptr;
 int g_decode_lds = 1;    // mafed_gemm_set_variant(760 / 761): register-direct / LDS-staged operand loads
 static int g_num_cus = 0;
 static int num_cus() {
@@ -658,7 +812,7 @@ extern "C" int mafed_decode_ln_qkv_fc1(const float* x, int M, int h, float eps, 
   MAFED_CHECK_ARG(mafed_decode_supported(M, h, n1), "decode_ln_qkv_fc1: unsupported shape M=%d h=%d n1=%d", M, h, n1);
   MAFED_CHECK_ARG(x && ln1_w && ln1_b && ln2_w && ln2_b && wqkv && bqkv && qkv_out && w1 && b1 && a_out, "decode_ln_qkv_fc1: null operand");
   MAFED_CHECK_ARG(qkv_ld >= 3 * (int64_t)h && qkv_ld % 4 == 0, "decode_ln_qkv_fc1: qkv_ld");
-  DecodeAArgs a{x, M, h, eps, ln1_w, ln1_b, ln2_w, ln2_b, (const bf16_t*)wqkv, bqkv, (bf16_t*)qkv_out, qkv_ld, (const bf16_t*)w1, b1, (bf16_t*)a_out, 3 * h, n1};
+  DecodeAArgs a{x, M, h, eps, ln1_w, ln1_b, ln2_w, ln2_b, (const bf16_t*)wqkv, bqkv, (bf16_t*)qkv_out, qkv_ld, (const bf16_t*)w1, b1, (bf16_t*)a_out, 3 * h, n1, g_decode_trace};
   const int mt = (M + 15) / 16, ks = h / 256;
   const size_t lds = (size_t)(16 * mt + 32) * (size_t)(h + 8) * 2;
   if (g_decode_lds && mt <= 2 && ks == 4 && lds <= 160 * 1024) {   // full-line loads through LDS (B <= 32 at h = 1024)
@@ -688,10 +842,39 @@ extern "C" int mafed_decode_ln_linear(const float* x, int M, int h, float eps, c
   MAFED_CHECK_ARG(mafed_decode_supported(M, h, 32) && N % 32 == 0 && N >= 32 && N <= (int64_t)1 << 30, "decode_ln_linear: unsupported shape M=%d h=%d N=%lld",
                   M, h, (long long)N);
   MAFED_CHECK_ARG(x && ln_w && ln_b && w && out && ldo >= N && ldo % 4 == 0, "decode_ln_linear: operands");
-  DecodeAArgs a{x, M, h, eps, ln_w, ln_b, ln_w, ln_b, (const bf16_t*)w, bias, (bf16_t*)out, ldo, (const bf16_t*)w, bias, (bf16_t*)out, (int)N, 0};
+  DecodeAArgs a{x, M, h, eps, ln_w, ln_b, ln_w, ln_b, (const bf16_t*)w, bias, (bf16_t*)out, ldo, (const bf16_t*)w, bias, (bf16_t*)out, (int)N, 0, nullptr};
   const int mt = (M + 15) / 16, ks = h / 256;
-  if (N % 128 == 0 && mt <= 2 && ks <= 4 && N / 128 >= 2 * num_cus()) decode_a_launch<4>(a, (hipStream_t)stream);
-  else decode_a_launch<1>(a, (hipStream_t)stream);
+  const size_t lds = (size_t)(16 * mt + 32) * (size_t)(h + 8) * 2;
+  if (g_decode_lds && mt <= 2 && ks == 4 && !bias && N % 16 == 0 && N / 16 >= 4 * num_cus()) {   // big vocabulary: persistent strips
+    const size_t ldsh = (size_t)(16 * mt + 32) * (size_t)(h + 8) * 2 + (size_t)8 * mt * 64 * 16;
+    const dim3 grid((unsigned)num_cus()), block(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (mt == 1) {
+      auto k = decode_head_kernel<1>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
+      k<<<grid, block, ldsh, st>>>(a);
+    } else {
+      auto k = decode_head_kernel<2>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
+      k<<<grid, block, ldsh, st>>>(a);
+    }
+  } else if (g_decode_lds && mt <= 2 && ks == 4 && lds <= 160 * 1024) {   // full-line loads through LDS: the layer kernel with one segment of N columns
+    const dim3 grid((unsigned)(N / 32)), block(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (mt == 1) {
+      auto k = decode_ln_qkv_fc1_lds_kernel<1, 4>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      k<<<grid, block, lds, st>>>(a);
+    } else {
+      auto k = decode_ln_qkv_fc1_lds_kernel<2, 4>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      k<<<grid, block, lds, st>>>(a);
+    }
+  } else if (N % 128 == 0 && mt <= 2 && ks <= 4 && N / 128 >= 2 * num_cus()) {
+    decode_a_launch<4>(a, (hipStream_t)stream);
+  } else {
+    decode_a_launch<1>(a, (hipStream_t)stream);
+  }
   MAFED_CHECK_LAUNCH("decode_ln_linear");
   return MAFED_OK;
 }

@@ -580,8 +580,12 @@ class VLPythiaForCausalLM(nn.Module):
                 ao = ops.attn_decode(cache.prefix[i], S0, cache.new[i], t, B, H, D, rot, cos, sin, cache.attention_mask, prerot=True)
                 x = ops.decode_out(x, ao, a, w(pre + "attention.dense.weight"), self._p(pre + "attention.dense.bias"),
                                    w(pre + "mlp.dense_4h_to_h.weight"), self._p(pre + "mlp.dense_4h_to_h.bias"), cache.workspace, out=x)
-            # (final LayerNorm folded into the head's launch -- ops.decode_ln_linear -- measured slower at V = 50k: 66 us against 48 for
-            #  the two launches, whose skinny kernel reads a bf16 row block per 16 vocabulary columns instead of an fp32 one per 128)
+            if B <= 32 and h == 1024 and cfg.vocab_size % 32 == 0 and cfg.vocab_size >= 16384:
+                # final LayerNorm + LM head as one persistent launch (decode_head_kernel: rows normalised once per CU, the vocabulary's
+                # weight strips streamed through LDS): 24 us against 48 for LayerNorm + the skinny product at V = 50k
+                return ops.decode_ln_linear(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
+                                            cfg.layer_norm_eps, w("embed_out.weight"))
+            # (other shapes: the one-slab-per-block forms of ops.decode_ln_linear are no faster than the two launches below)
             lnf, _, _, _ = ops.layernorm_fwd(x, self._p("gpt_neox.final_layer_norm.weight"), self._p("gpt_neox.final_layer_norm.bias"),
                                              None, None, cfg.layer_norm_eps, cd, save_stats=False)
             return ops.gemm(lnf, w("embed_out.weight"), False, True)

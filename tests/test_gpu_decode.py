@@ -287,7 +287,8 @@ def test_generate_410m_fused_decode_tracks_the_separate_launches():
 
 @pytest.mark.parametrize("M,h,N", [(32, 1024, 50304), (8, 1024, 50304), (40, 1024, 50304), (3, 768, 50304), (32, 1024, 256), (2, 256, 96), (16, 2048, 50304)])
 def test_decode_ln_linear_equals_layernorm_then_head(M, h, N):
-    """Final LayerNorm + LM head as one launch (wide 128-column blocks for the 50k vocabulary at M <= 32, 32-column blocks else)."""
+    """Final LayerNorm + LM head as one launch: the persistent strip kernel for a big vocabulary at h = 1024, M <= 32 (rows normalised once
+    per CU, weight strips streamed through LDS), the one-slab-per-block forms else."""
     from mafed_amd import ops
     g = torch.Generator().manual_seed(M + h + N)
     x = (torch.randn(M, h, generator=g) * 2.0 - 0.5).to(DEV)
