@@ -332,3 +332,26 @@ def test_replay_buffer_refuses_an_empty_rank_shard():
     empty.add(data)
     with pytest.raises(RuntimeError, match="empty shard"):
         empty._draw()
+
+
+def test_fused_squares_query_is_host_logic():
+    """mafed_gemm_grouped_fuses_sumsq needs no GPU (it only runs the dispatcher's pick): the 410M weight-gradient group fuses its squares,
+    the h = 768 / 2048 groups (256 x 256-tile kernel) and a lone small product do not -- the model then keeps the norm hook's range pass
+    (the regression this guards cost the 160M / 1.4B-shape steps 15 - 27 % for most of round 4)."""
+    import ctypes
+    from mafed_amd import _lib
+    lib = _lib.load()
+    rows = 32 * 288
+
+    def fuses(shapes):
+        n = len(shapes)
+        arr = lambda k: (ctypes.c_int64 * n)(*[int(s[k]) for s in shapes])
+        Ms, Ns, Ks = arr(0), arr(1), arr(2)
+        return bool(lib.mafed_gemm_grouped_fuses_sumsq(_lib.BF16, 1, 0, _lib.F32, ctypes.cast(Ms, ctypes.c_void_p), ctypes.cast(Ns, ctypes.c_void_p),
+                                                       ctypes.cast(Ks, ctypes.c_void_p), n))
+
+    layer = lambda h: [(3 * h, h, rows), (h, h, rows), (4 * h, h, rows), (h, 4 * h, rows)]
+    assert fuses(layer(1024) * 2)
+    assert not fuses(layer(2048) * 2)
+    assert not fuses(layer(768) * 2)
+    assert not fuses(layer(1024)[1:2])
