@@ -1077,6 +1077,10 @@ class _DecodeCache:
         """Rotate the prefix keys in place (call once per prefill: the prefix must hold what the QKV GEMMs wrote)."""
         cfg = self._model.config
         cos, sin = self._model.rotary_tables(self.S0 + self.cap)
+        whole = getattr(self, "prefix_storage", None)   # the graphed decode keeps every layer's prefix in ONE tensor: one launch for all
+        if whole is not None:
+            ops.rotate_k_rows_(whole, whole.shape[0] * self.B, self.S0, cfg.num_attention_heads, cfg.head_dim, cfg.rotary_ndims, cos, sin)
+            return
         for p in self.prefix:
             ops.rotate_k_rows_(p, self.B, self.S0, cfg.num_attention_heads, cfg.head_dim, cfg.rotary_ndims, cos, sin)
 
@@ -1092,12 +1096,14 @@ class _GraphedDecode:
         S0 = cfg.num_vision_tokens + T
         n = 3 * cfg.num_attention_heads * cfg.head_dim
         self.model, self.B, self.T, self.S0, self.max_new = model, B, T, S0, max_new
-        self.prefix = [torch.empty((B * S0, n), dtype=cd, device=dev) for _ in range(cfg.num_hidden_layers)]
+        self.prefix_storage = torch.empty((cfg.num_hidden_layers, B * S0, n), dtype=cd, device=dev)   # [L, B*S0, 3h]: rotated by one launch
+        self.prefix = list(self.prefix_storage.unbind(0))
         self.am = torch.ones((B, T), dtype=torch.int64, device=dev)
         self.first_logits = torch.zeros((B, cfg.vocab_size), dtype=cd if cd != torch.float32 else torch.float32, device=dev)
         self.tokens = torch.zeros((B, max_new), dtype=torch.int64, device=dev)
         model.rotary_tables(S0 + max(1, max_new))  # built (host -> device copy) before the capture, not inside it
-        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am, fused=getattr(model, "fused_decode", True))   # (rotates the still-empty prefix once: harmless)
+        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am, fused=getattr(model, "fused_decode", True))
+        self.cache.prefix_storage = self.prefix_storage   # (rotates the still-empty prefix once: harmless)
         eos, pad = eos_token_id, pad_token_id
 
         def body():
