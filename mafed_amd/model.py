@@ -520,8 +520,13 @@ class VLPythiaForCausalLM(nn.Module):
             gen_all = gd.run(feats, ids, am)
             new_tokens = list(gen_all.unbind(1))
         else:
-            st = self._engine_forward(feats, ids, am, None, False, train=False, keep_qkv=True, last_only=True)
-            cache = _DecodeCache(self, [l["qkv"] for l in st["layers"]], B, st["S"], max_new_tokens, am, fused=getattr(self, "fused_decode", True))
+            # every layer's fused-QKV output lands in one tensor (the K/V cache's prefix): its keys are then rotated by ONE launch
+            cfg_ = self.config
+            S_ = cfg_.num_vision_tokens + T
+            store = torch.empty((cfg_.num_hidden_layers, B * S_, 3 * cfg_.num_attention_heads * cfg_.head_dim), dtype=self.compute_dtype, device=dev)
+            st = self._engine_forward(feats, ids, am, None, False, train=False, qkv_out=list(store.unbind(0)), last_only=True)
+            cache = _DecodeCache(self, list(store.unbind(0)), B, st["S"], max_new_tokens, am, fused=getattr(self, "fused_decode", True),
+                                 prefix_storage=store)
             nxt = pick(st["logits"][:, -1, :])
             for t in range(max_new_tokens - 1):
                 nxt = pick(self._engine_decode_step(nxt, t, cache))
@@ -1027,8 +1032,10 @@ class _DecodeCache:
     """K/V cache of a greedy decode: per layer the prefill's [B*S0, 3*H*D] fused-QKV output (kept as written -- no split, no
     transpose, k un-rotated) and a [B, cap, 3*H*D] tensor that receives one row per generated token."""
 
-    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor, prerotate: bool = True, fused: bool = True):
+    def __init__(self, model, prefix, B: int, S0: int, cap: int, attention_mask: torch.Tensor, prerotate: bool = True, fused: bool = True,
+                 prefix_storage: Optional[torch.Tensor] = None):
         self.prefix, self.B, self.S0, self.cap, self.attention_mask = prefix, B, S0, max(1, cap), attention_mask
+        self.prefix_storage = prefix_storage   # [L, B*S0, 3h] holding every entry of `prefix` (then one rotation launch serves all layers)
         cfg = model.config
         n = 3 * cfg.num_attention_heads * cfg.head_dim
         self.new = [torch.zeros((B, self.cap, n), dtype=prefix[0].dtype, device=prefix[0].device) for _ in prefix]
@@ -1077,7 +1084,7 @@ class _DecodeCache:
         """Rotate the prefix keys in place (call once per prefill: the prefix must hold what the QKV GEMMs wrote)."""
         cfg = self._model.config
         cos, sin = self._model.rotary_tables(self.S0 + self.cap)
-        whole = getattr(self, "prefix_storage", None)   # the graphed decode keeps every layer's prefix in ONE tensor: one launch for all
+        whole = self.prefix_storage   # every layer's prefix in ONE tensor: one launch for all
         if whole is not None:
             ops.rotate_k_rows_(whole, whole.shape[0] * self.B, self.S0, cfg.num_attention_heads, cfg.head_dim, cfg.rotary_ndims, cos, sin)
             return
@@ -1102,8 +1109,8 @@ class _GraphedDecode:
         self.first_logits = torch.zeros((B, cfg.vocab_size), dtype=cd if cd != torch.float32 else torch.float32, device=dev)
         self.tokens = torch.zeros((B, max_new), dtype=torch.int64, device=dev)
         model.rotary_tables(S0 + max(1, max_new))  # built (host -> device copy) before the capture, not inside it
-        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am, fused=getattr(model, "fused_decode", True))
-        self.cache.prefix_storage = self.prefix_storage   # (rotates the still-empty prefix once: harmless)
+        self.cache = _DecodeCache(model, self.prefix, B, S0, max_new, self.am, fused=getattr(model, "fused_decode", True),
+                                  prefix_storage=self.prefix_storage)   # (rotates the still-empty prefix once: harmless)
         eos, pad = eos_token_id, pad_token_id
 
         def body():
