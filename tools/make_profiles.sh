@@ -5,6 +5,7 @@
 #   bench_kernel_by_shape.csv  per (kernel, grid) launch statistics from the same trace
 #   timeline.txt               tools/trace_timeline.py on the same trace (overlap depth, per-queue mix, idle gaps)
 #   pmc_traffic.json           fabric-side bytes per GEMM launch, per shape, from FETCH_SIZE / WRITE_SIZE (separate --pmc passes)
+#   decode.txt, decode_kernel_stats.csv, decode_pmc.json, decode_flow_trace.txt   the validation decode (skip with SKIP_DECODE=1)
 set -e
 OUT=gpurun_out/profiles_new
 mkdir -p $OUT
@@ -83,3 +84,12 @@ python3 tools/pmc_summary.py gpurun_out/prof_attn_all attn_ > $OUT/attn_pmc.json
 rm -rf gpurun_out/prof_attn_all
 python3 tools/attn_bench.py > $OUT/attn_isolated.txt 2>/dev/null
 cat $OUT/bench_line.json | cut -c1-400
+# validation decode: bench of the decode forms at three model sizes, isolated kernels, rocprofv3 kernel statistics, fabric bytes
+# per launch (separate --pmc passes) and the in-kernel time stamps
+if [ "$SKIP_DECODE" != "1" ]; then
+  { for m in 410m 160m 1.4b; do timeout -k 10 300 python3 tools/decode_bench.py $m 2>/dev/null; done; echo; timeout -k 10 300 python3 tools/decode_kernel_bench.py 2>/dev/null;
+    echo; timeout -k 10 120 python3 tools/decode_ab_trace.py 2>/dev/null; echo; timeout -k 10 120 python3 tools/decode_out_trace.py 2>/dev/null; } > $OUT/decode.txt
+  bash tools/decode_profile.sh gpurun_out/decode_prof > /dev/null 2>&1 && cp gpurun_out/decode_prof/decode_kernel_stats.csv $OUT/decode_kernel_stats.csv
+  bash tools/decode_pmc.sh gpurun_out/decode_pmc > /dev/null 2>&1 && cp gpurun_out/decode_pmc/decode_pmc.json $OUT/decode_pmc.json
+  { timeout -k 10 120 python3 tools/decode_flow_trace.py 2>/dev/null; echo; timeout -k 10 120 python3 tools/decode_pair_trace.py 2>/dev/null; } > $OUT/decode_flow_trace.txt
+fi
